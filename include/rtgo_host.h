@@ -1,0 +1,44 @@
+/*
+ * rtgo_host.h -- small C view of the C++ host surface (librtgo_host.so: Scene / Shape / ShapeFactory / Primitive /
+ * SurfaceLight / Renderer, namespace engine::host, mirroring engine/scene.h, shapefactory.h, primitive.h, light.h,
+ * renderer.h of the reference).  It exists so that Python drivers (bench.py, tests) can ask the PRODUCT host code for
+ * the flattened scene tables and run the headless Renderer; C++ users include the headers under raytracingo_amd/host/ directly.
+ */
+#ifndef RTGO_HOST_H
+#define RTGO_HOST_H
+
+#include "rtgo.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Flattened scene exactly as Renderer::CreateShapes / CreateRayGen / CreateMiss / WriteLights hand it to the ABI
+   (engine/renderer.cpp:321-336, 386-453, 655-677). */
+typedef struct rtgo_host_scene {
+    uint32_t n_prims;
+    uint32_t n_lights;
+    rtgo_prim prims[RTGO_MAX_PRIMS];
+    rtgo_aabb aabbs[RTGO_MAX_PRIMS];
+    rtgo_light lights[RTGO_MAX_LIGHTS];
+    float eye[3], U[3], V[3], W[3];
+    float background[3];
+} rtgo_host_scene;
+
+/* scene_name: the --scene values of engine/main.cpp:44-52 (plateau, slide, cornell, mirror_spheres, soft_mirrors,
+   window, balls, checkered).  returns 0, or RTGO_E_INVALID for an unknown name. */
+int rtgo_host_scene_build(const char* scene_name, uint32_t width, uint32_t height, rtgo_host_scene* out);
+
+/* Headless engine::host::Renderer run: `frames` progressive frames of scene_name at width x height.
+   mode: "path" or "distributed" (engine/main.cpp:83-103); sample = --sample; ambient = --useAmbient.
+   host_image (uchar4, may be NULL) / host_accum (float4, may be NULL) receive the last frame; stats may be NULL.
+   returns 0 or an RTGO_E_* code; message via rtgo_host_last_error(). */
+int rtgo_host_render(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient,
+                     int frames, int device, void* host_image, void* host_accum, rtgo_stats* stats);
+
+const char* rtgo_host_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

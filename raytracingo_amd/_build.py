@@ -1,0 +1,68 @@
+"""Build the native parts of raytracingo_amd in-tree (the .so files travel to the GPU box with the snapshot).
+
+  librtgo_hip.so   csrc/rtgo_capi.hip + rtgo_device.h   hipcc --offload-arch=gfx950   (the product: C ABI + kernels)
+  librtgo_host.so  host/*.cpp                            g++                           (Scene/Shape/Renderer mirror)
+  rtgo_engine      host/main.cpp                         g++                           (headless CLI of engine/main.cpp)
+"""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+# -ffp-contract=off: one IEEE rounding per operation, the same statement of the arithmetic as the oracle
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def build_hip(force=False, verbose=False):
+    src = os.path.join(PKG, "csrc", "rtgo_capi.hip")
+    deps = [src, os.path.join(PKG, "csrc", "rtgo_device.h"), os.path.join(ROOT, "include", "rtgo.h")]
+    out = os.path.join(PKG, "librtgo_hip.so")
+    if force or _stale(out, deps):
+        cmd = [HIPCC] + HIP_FLAGS + ["-o", out, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
+def host_sources():
+    d = os.path.join(PKG, "host")
+    return sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".cpp") and f != "main.cpp")
+
+
+def build_host(force=False, verbose=False):
+    d = os.path.join(PKG, "host")
+    if not os.path.isdir(d):
+        return None
+    srcs = host_sources()
+    hdrs = [os.path.join(d, f) for f in os.listdir(d) if f.endswith(".h")] + [os.path.join(ROOT, "include", "rtgo.h"),
+                                                                              os.path.join(ROOT, "include", "rtgo_host.h")]
+    out = os.path.join(PKG, "librtgo_host.so")
+    if srcs and (force or _stale(out, srcs + hdrs)):
+        cmd = ["g++"] + HOST_FLAGS + ["-shared", "-I" + os.path.join(ROOT, "include"), "-I" + d, "-o", out] + srcs + ["-L" + PKG, "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    exe = os.path.join(PKG, "rtgo_engine")
+    main = os.path.join(d, "main.cpp")
+    if os.path.exists(main) and (force or _stale(exe, [main, out] + hdrs)):
+        cmd = ["g++"] + HOST_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + d, "-o", exe, main,
+                                      "-L" + PKG, "-lrtgo_host", "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
+def build_all(force=False, verbose=False):
+    return build_hip(force, verbose), build_host(force, verbose)

@@ -1,0 +1,432 @@
+// rtgo_capi.hip -- the C ABI of include/rtgo.h over the gfx950 kernels of rtgo_device.h.
+// Host side of the drop-in boundary: where the reference's Renderer calls the OptiX host API, a port calls these.
+// There is no CPU fallback anywhere in this file: every path ends in a HIP launch or an error code.
+#include "../../include/rtgo.h"
+#include "rtgo_device.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rtgo;
+
+static_assert(sizeof(rtgo_prim) == sizeof(PrimIn), "rtgo_prim layout");
+static_assert(sizeof(rtgo_prim) == 108, "rtgo_prim is type + HitGroupData (104 B, params.h:103-110)");
+static_assert(sizeof(rtgo_light) == sizeof(LightRec) && sizeof(rtgo_light) == 64, "SurfaceLight is 64 B");
+static_assert(sizeof(rtgo_aabb) == 24, "OptixAabb is 24 B");
+static_assert(RTGO_MAX_PRIMS == kMaxPrims && RTGO_MAX_LIGHTS == kMaxLights, "limits");
+
+struct rtgo_ctx {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool ev_pending = false;
+    // scene
+    uint32_t n_prims = 0;
+    PrimIn* d_prims_in = nullptr;
+    float* d_aabb = nullptr;
+    float4* d_nodes = nullptr;
+    float4* d_prims = nullptr;
+    int* d_meta = nullptr;
+    int lbvh_depth = 0;
+    LightRec* d_lights = nullptr;
+    int n_lights = 0;
+    bool have_camera = false;
+    v3 eye{0, 0, 0}, U{0, 0, 0}, V{0, 0, 0}, W{0, 0, 0}, bg{0, 0, 0};
+    // output
+    float4* d_accum = nullptr;
+    uchar4* d_image = nullptr;
+    size_t pixels = 0;
+    bool own_output = false;
+    // queue + counters
+    unsigned int* d_queue = nullptr;
+    unsigned long long* d_counters = nullptr;  // 8 x u64
+    float total_ms = 0.0f, last_ms = 0.0f;
+    uint32_t launches = 0;
+    std::string err;
+};
+
+static std::string g_create_error;
+
+static int fail(rtgo_ctx* c, int code, const std::string& msg)
+{
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define RTGO_HIP(ctx, call)                                                                                       \
+    do {                                                                                                          \
+        hipError_t e_ = (call);                                                                                   \
+        if (e_ != hipSuccess)                                                                                     \
+            return fail(ctx, RTGO_E_HIP_BASE + (int)e_,                                                           \
+                        std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+    } while (0)
+
+extern "C" {
+
+uint32_t rtgo_abi_version(void) { return RTGO_ABI_VERSION; }
+
+const char* rtgo_last_error(const rtgo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+uint32_t rtgo_local_rows(uint32_t h, uint32_t band_h, uint32_t n_ranks, uint32_t rank)
+{
+    if (n_ranks <= 1) return h;
+    if (band_h == 0) band_h = kTileH;
+    const uint32_t bands = (h + band_h - 1) / band_h;
+    uint32_t rows = 0;
+    for (uint32_t b = rank; b < bands; b += n_ranks) {
+        const uint32_t r0 = b * band_h;
+        rows += (r0 + band_h <= h) ? band_h : (h - r0);
+    }
+    return rows;
+}
+
+int rtgo_create(int device, rtgo_ctx** out)
+{
+    if (!out) return fail(nullptr, RTGO_E_INVALID, "rtgo_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, RTGO_E_NO_DEVICE, "rtgo_create: no HIP device (this library has no CPU path)");
+    if (device < 0 || device >= count) return fail(nullptr, RTGO_E_INVALID, "rtgo_create: bad device index");
+    RTGO_HIP(nullptr, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RTGO_HIP(nullptr, hipGetDeviceProperties(&prop, device));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, RTGO_E_NO_DEVICE,
+                    std::string("rtgo_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    rtgo_ctx* c = new rtgo_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    hipError_t err = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreate(&c->ev_start);
+    if (err == hipSuccess) err = hipEventCreate(&c->ev_stop);
+    if (err == hipSuccess) err = hipMalloc(&c->d_queue, sizeof(unsigned int));
+    if (err == hipSuccess) err = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long));
+    if (err == hipSuccess) err = hipMalloc(&c->d_lights, kMaxLights * sizeof(LightRec));
+    if (err == hipSuccess) err = hipMemset(c->d_lights, 0, kMaxLights * sizeof(LightRec));
+    if (err == hipSuccess) err = hipMalloc(&c->d_meta, 4 * sizeof(int));
+    // the megakernel may use most of the 160 KiB LDS of a CU
+    const int max_lds = 160 * 1024;
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (err != hipSuccess) {
+        std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
+        rtgo_destroy(c);
+        return fail(nullptr, RTGO_E_HIP_BASE + (int)err, m);
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return RTGO_OK;
+}
+
+int rtgo_destroy(rtgo_ctx* c)
+{
+    if (!c) return RTGO_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    (void)hipFree(c->d_prims_in);
+    (void)hipFree(c->d_aabb);
+    (void)hipFree(c->d_nodes);
+    (void)hipFree(c->d_prims);
+    (void)hipFree(c->d_meta);
+    (void)hipFree(c->d_lights);
+    if (c->own_output) {
+        (void)hipFree(c->d_accum);
+        (void)hipFree(c->d_image);
+    }
+    (void)hipFree(c->d_queue);
+    (void)hipFree(c->d_counters);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return RTGO_OK;
+}
+
+int rtgo_set_stream(rtgo_ctx* c, void* hip_stream)
+{
+    if (!c) return RTGO_E_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RTGO_OK;
+}
+
+int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, uint32_t n)
+{
+    if (!c || !prims) return fail(c, RTGO_E_INVALID, "rtgo_set_scene: NULL argument");
+    if (n == 0 || n > RTGO_MAX_PRIMS)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: primitive count must be in [1, " + std::to_string(RTGO_MAX_PRIMS) + "]");
+    for (uint32_t i = 0; i < n; ++i)
+        if (prims[i].type > RTGO_SPHERE) return fail(c, RTGO_E_INVALID, "rtgo_set_scene: unknown primitive type");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_prims_in);
+    (void)hipFree(c->d_aabb);
+    (void)hipFree(c->d_nodes);
+    (void)hipFree(c->d_prims);
+    c->d_prims_in = nullptr;
+    c->d_aabb = nullptr;
+    c->d_nodes = nullptr;
+    c->d_prims = nullptr;
+    c->n_prims = 0;
+    RTGO_HIP(c, hipMalloc(&c->d_prims_in, n * sizeof(PrimIn)));
+    RTGO_HIP(c, hipMalloc(&c->d_aabb, n * 6 * sizeof(float)));
+    RTGO_HIP(c, hipMalloc(&c->d_nodes, (2 * n - 1) * 2 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->d_prims, n * 6 * sizeof(float4)));
+    RTGO_HIP(c, hipMemcpyAsync(c->d_prims_in, prims, n * sizeof(PrimIn), hipMemcpyHostToDevice, c->stream));
+    if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), 0, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
+                       c->d_nodes, c->d_prims, c->d_meta);
+    RTGO_HIP(c, hipGetLastError());
+    int depth = 0;
+    RTGO_HIP(c, hipMemcpyAsync(&depth, c->d_meta, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    c->lbvh_depth = depth;
+    if (depth > kStackDepth)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
+                                               std::to_string(kStackDepth) + ")");
+    c->n_prims = n;
+    return RTGO_OK;
+}
+
+int rtgo_set_camera(rtgo_ctx* c, const float eye[3], const float U[3], const float V[3], const float W[3])
+{
+    if (!c || !eye || !U || !V || !W) return fail(c, RTGO_E_INVALID, "rtgo_set_camera: NULL argument");
+    c->eye = v3{eye[0], eye[1], eye[2]};
+    c->U = v3{U[0], U[1], U[2]};
+    c->V = v3{V[0], V[1], V[2]};
+    c->W = v3{W[0], W[1], W[2]};
+    c->have_camera = true;
+    return RTGO_OK;
+}
+
+int rtgo_set_background(rtgo_ctx* c, const float rgb[3])
+{
+    if (!c || !rgb) return fail(c, RTGO_E_INVALID, "rtgo_set_background: NULL argument");
+    c->bg = v3{rgb[0], rgb[1], rgb[2]};
+    return RTGO_OK;
+}
+
+int rtgo_set_lights(rtgo_ctx* c, const rtgo_light* lights, int n)
+{
+    if (!c || n < 0 || (n > 0 && !lights)) return fail(c, RTGO_E_INVALID, "rtgo_set_lights: bad argument");
+    if (n > RTGO_MAX_LIGHTS) n = RTGO_MAX_LIGHTS;  // Renderer::WriteLights copies at most MAX_LIGHTS (renderer.cpp:661)
+    RTGO_HIP(c, hipSetDevice(c->device));
+    if (n > 0) RTGO_HIP(c, hipMemcpyAsync(c->d_lights, lights, n * sizeof(rtgo_light), hipMemcpyHostToDevice, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    c->n_lights = n;
+    return RTGO_OK;
+}
+
+int rtgo_resize(rtgo_ctx* c, size_t pixels)
+{
+    if (!c || pixels == 0) return fail(c, RTGO_E_INVALID, "rtgo_resize: bad argument");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->own_output) {
+        (void)hipFree(c->d_accum);
+        (void)hipFree(c->d_image);
+    }
+    c->d_accum = nullptr;
+    c->d_image = nullptr;
+    c->own_output = false;
+    c->pixels = 0;
+    RTGO_HIP(c, hipMalloc(&c->d_accum, pixels * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->d_image, pixels * sizeof(uchar4)));
+    RTGO_HIP(c, hipMemsetAsync(c->d_accum, 0, pixels * sizeof(float4), c->stream));
+    RTGO_HIP(c, hipMemsetAsync(c->d_image, 0, pixels * sizeof(uchar4), c->stream));
+    c->own_output = true;
+    c->pixels = pixels;
+    return RTGO_OK;
+}
+
+int rtgo_bind_output(rtgo_ctx* c, void* d_accum, void* d_image, size_t pixels)
+{
+    if (!c || !d_accum || !d_image || pixels == 0) return fail(c, RTGO_E_INVALID, "rtgo_bind_output: bad argument");
+    if (((uintptr_t)d_accum & 15u) || ((uintptr_t)d_image & 3u))
+        return fail(c, RTGO_E_INVALID, "rtgo_bind_output: accum must be 16-byte aligned, image 4-byte aligned");
+    if (c->own_output) {
+        (void)hipFree(c->d_accum);
+        (void)hipFree(c->d_image);
+    }
+    c->d_accum = (float4*)d_accum;
+    c->d_image = (uchar4*)d_image;
+    c->own_output = false;
+    c->pixels = pixels;
+    return RTGO_OK;
+}
+
+int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
+{
+    if (!c || !f) return fail(c, RTGO_E_INVALID, "rtgo_launch: NULL argument");
+    if (c->n_prims == 0) return fail(c, RTGO_E_STATE, "rtgo_launch: no scene (call rtgo_set_scene)");
+    if (!c->have_camera) return fail(c, RTGO_E_STATE, "rtgo_launch: no camera (call rtgo_set_camera)");
+    if (!c->d_accum || !c->d_image) return fail(c, RTGO_E_STATE, "rtgo_launch: no output (call rtgo_resize or rtgo_bind_output)");
+    if (f->image_width == 0 || f->image_height == 0 || f->sqrt_spp <= 0)
+        return fail(c, RTGO_E_INVALID, "rtgo_launch: image size and sqrt_spp must be positive");
+    if (f->max_trace_depth < 0 || f->max_trace_depth > kMaxLevels)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: max_trace_depth must be in [0, 5] (reference uses 5, renderer.cpp:616)");
+    if (!f->path_tracing && c->n_lights < 1)
+        return fail(c, RTGO_E_STATE, "rtgo_launch: distributed mode needs at least one surface light");
+    LaunchParams p;
+    std::memset(&p, 0, sizeof p);
+    p.W = f->image_width;
+    p.H = f->image_height;
+    p.x0 = f->x0;
+    p.y0 = f->y0;
+    p.w = f->w ? f->w : f->image_width;
+    p.h = f->h ? f->h : f->image_height;
+    if ((uint64_t)p.x0 + p.w > p.W || (uint64_t)p.y0 + p.h > p.H) return fail(c, RTGO_E_INVALID, "rtgo_launch: window outside the image");
+    p.band_h = f->band_h ? f->band_h : kTileH;
+    p.n_ranks = f->n_ranks ? f->n_ranks : 1;
+    p.rank = f->rank;
+    if (p.rank >= p.n_ranks) return fail(c, RTGO_E_INVALID, "rtgo_launch: rank >= n_ranks");
+    p.local_rows = rtgo_local_rows(p.h, p.band_h, p.n_ranks, p.rank);
+    if ((size_t)p.local_rows * p.w > c->pixels) return fail(c, RTGO_E_INVALID, "rtgo_launch: output buffer too small for this window");
+    p.tiles_x = (p.w + kTileW - 1) / kTileW;
+    p.n_tiles = p.tiles_x * ((p.local_rows + kTileH - 1) / kTileH);
+    p.nodes = c->d_nodes;
+    p.prims = c->d_prims;
+    p.lights = c->d_lights;
+    p.accum = c->d_accum;
+    p.image = c->d_image;
+    p.queue = c->d_queue;
+    p.counters = c->d_counters;
+    p.n_prims = (int)c->n_prims;
+    p.n_nodes = 2 * (int)c->n_prims - 1;
+    p.n_lights = c->n_lights;
+    p.sqrt_spp = f->sqrt_spp;
+    p.max_depth = f->max_trace_depth;
+    p.frame = f->frame_count;
+    p.ambient = f->use_ambient ? 1 : 0;
+    p.eye = c->eye;
+    p.U = c->U;
+    p.V = c->V;
+    p.Wv = c->W;
+    p.bg = c->bg;
+    if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
+
+    const size_t lds = (size_t)(2 * p.n_nodes + 6 * p.n_prims) * sizeof(float4) + (size_t)kStackDepth * kBlock * sizeof(float2) +
+                       (size_t)kMaxLights * sizeof(LightRec);
+    int blocks_per_cu = (int)((160 * 1024) / lds);
+    if (blocks_per_cu < 1) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
+    if (blocks_per_cu > 4) blocks_per_cu = 4;
+    unsigned int grid = (unsigned int)(c->num_cus * blocks_per_cu);
+    const unsigned int need = (p.n_tiles + (kBlock / 64) - 1) / (kBlock / 64);
+    if (grid > need) grid = need;
+
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
+    RTGO_HIP(c, hipEventRecord(c->ev_start, c->stream));
+    const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
+    if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+    else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+    else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+    else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+    RTGO_HIP(c, hipGetLastError());
+    RTGO_HIP(c, hipEventRecord(c->ev_stop, c->stream));
+    c->ev_pending = true;
+    c->launches++;
+    return RTGO_OK;
+}
+
+int rtgo_sync(rtgo_ctx* c)
+{
+    if (!c) return RTGO_E_INVALID;
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->ev_pending) {
+        float ms = 0.0f;
+        RTGO_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
+        c->last_ms = ms;
+        c->total_ms += ms;
+        c->ev_pending = false;
+    }
+    return RTGO_OK;
+}
+
+static int copy_out(rtgo_ctx* c, void* host, const void* dev, size_t bytes, size_t elem)
+{
+    if (!c || !host) return fail(c, RTGO_E_INVALID, "rtgo_read: NULL argument");
+    if (!dev) return fail(c, RTGO_E_STATE, "rtgo_read: no output buffer");
+    if (bytes > c->pixels * elem) return fail(c, RTGO_E_INVALID, "rtgo_read: more bytes than the output holds");
+    int rc = rtgo_sync(c);
+    if (rc) return rc;
+    RTGO_HIP(c, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    return RTGO_OK;
+}
+
+int rtgo_read_image(rtgo_ctx* c, void* host, size_t bytes) { return copy_out(c, host, c ? c->d_image : nullptr, bytes, sizeof(uchar4)); }
+int rtgo_read_accum(rtgo_ctx* c, void* host, size_t bytes) { return copy_out(c, host, c ? c->d_accum : nullptr, bytes, sizeof(float4)); }
+
+int rtgo_write_accum(rtgo_ctx* c, const void* host, size_t bytes)
+{
+    if (!c || !host) return fail(c, RTGO_E_INVALID, "rtgo_write_accum: NULL argument");
+    if (!c->d_accum) return fail(c, RTGO_E_STATE, "rtgo_write_accum: no output buffer");
+    if (bytes > c->pixels * sizeof(float4)) return fail(c, RTGO_E_INVALID, "rtgo_write_accum: too many bytes");
+    int rc = rtgo_sync(c);
+    if (rc) return rc;
+    RTGO_HIP(c, hipMemcpy(c->d_accum, host, bytes, hipMemcpyHostToDevice));
+    return RTGO_OK;
+}
+
+int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
+{
+    if (!c || !out) return fail(c, RTGO_E_INVALID, "rtgo_get_stats: NULL argument");
+    int rc = rtgo_sync(c);
+    if (rc) return rc;
+    unsigned long long h[8];
+    RTGO_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    out->rays_total = h[0];
+    out->rays_occlusion = h[1];
+    out->node_visits = h[2];
+    out->prim_tests = h[3];
+    out->hits = h[4];
+    out->last_launch_ms = c->last_ms;
+    out->total_launch_ms = c->total_ms;
+    out->launches = c->launches;
+    out->lbvh_depth = (uint32_t)c->lbvh_depth;
+    return RTGO_OK;
+}
+
+int rtgo_reset_stats(rtgo_ctx* c)
+{
+    if (!c) return RTGO_E_INVALID;
+    int rc = rtgo_sync(c);
+    if (rc) return rc;
+    RTGO_HIP(c, hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
+    c->total_ms = 0.0f;
+    c->last_ms = 0.0f;
+    c->launches = 0;
+    return RTGO_OK;
+}
+
+int rtgo_read_bvh(rtgo_ctx* c, void* host_nodes, size_t node_bytes, void* host_inv, size_t inv_bytes, void* host_aabbs, size_t aabb_bytes)
+{
+    if (!c) return RTGO_E_INVALID;
+    if (c->n_prims == 0) return fail(c, RTGO_E_STATE, "rtgo_read_bvh: no scene");
+    const size_t n = c->n_prims;
+    if ((host_nodes && node_bytes != (2 * n - 1) * 32) || (host_inv && inv_bytes != n * 48) || (host_aabbs && aabb_bytes != n * 24))
+        return fail(c, RTGO_E_INVALID, "rtgo_read_bvh: buffer sizes must be (2n-1)*32, n*48, n*24");
+    int rc = rtgo_sync(c);
+    if (rc) return rc;
+    if (host_nodes) RTGO_HIP(c, hipMemcpy(host_nodes, c->d_nodes, node_bytes, hipMemcpyDeviceToHost));
+    if (host_inv) {
+        std::vector<float4> tmp(6 * n);
+        RTGO_HIP(c, hipMemcpy(tmp.data(), c->d_prims, 6 * n * sizeof(float4), hipMemcpyDeviceToHost));
+        float* o = (float*)host_inv;
+        for (size_t i = 0; i < n; ++i) std::memcpy(o + 12 * i, &tmp[6 * i], 48);
+    }
+    if (host_aabbs) RTGO_HIP(c, hipMemcpy(host_aabbs, c->d_aabb, aabb_bytes, hipMemcpyDeviceToHost));
+    return RTGO_OK;
+}
+
+}  // extern "C"

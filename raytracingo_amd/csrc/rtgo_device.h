@@ -1,0 +1,885 @@
+// rtgo_device.h -- gfx950 device code of the RayTracinGO hot path: the scene-preparation/LBVH-build kernel and the
+// render megakernel that replaces the OptiX pipeline of engine/kernel.cu (raygen + traversal + 4 intersection
+// programs + 2 closest-hit programs + miss + accumulation), all in one launch.
+//
+// Written for CDNA4 only (wave64, LDS-resident scene, per-lane LDS traversal stack).  No MFMA: there is no dense
+// contraction on this path.  Arithmetic follows the reference's IEEE-float32 statement operation by operation (this
+// translation unit is compiled with -ffp-contract=off); the few places where the hoisted form differs from the
+// literal one only in the sign of a zero are noted.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtgo {
+
+constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kStackDepth = 24;      // per-lane traversal stack entries (LBVH depth is checked against it at build)
+constexpr int kTileW = 16, kTileH = 4;  // one wave = 16x4 pixels: 256-byte float4 rows, 4-row bands for multi-GPU
+constexpr int kMaxPrims = 512;
+constexpr int kMaxLights = 10;
+constexpr int kMaxLevels = 5;        // bounce records kept per path (maxTraceDepth <= 5)
+constexpr float kPi = 3.14159265358979323846f;  // M_PIf, sutil/vec_math.h:43
+
+struct v3 {
+    float x, y, z;
+};
+
+// ---- LDS/global scene layout ----------------------------------------------------------------------------------
+// node record, 32 B = 2 x float4:  q0 = (bmin.xyz, bits(left)), q1 = (bmax.xyz, bits(right))
+//   internal nodes [0, n-2], leaves [n-1, 2n-2]; leaf: left = primitive (SBT) index, right = -1
+// primitive record, 96 B = 6 x float4:
+//   q0..q2 = rows 0..2 of M^-1 (row 3 is never needed: TransformRay/TransformNormal drop w, kernel.cu:125-142)
+//   q3 = (kd.xyz, specularity)   q4 = (kr.xyz, bits(type))   q5 = (Le.xyz, 0)
+struct LightRec {
+    float corner[3], v1[3], v2[3], normal[3], color[3], falloff;  // device::SurfaceLight, params.h:73-87
+};
+
+struct LaunchParams {
+    const float4* nodes;
+    const float4* prims;
+    const LightRec* lights;
+    float4* accum;
+    uchar4* image;
+    unsigned int* queue;            // tile queue head (zeroed before every launch)
+    unsigned long long* counters;   // [0] rays_total [1] rays_occlusion [2] node_visits [3] prim_tests [4] hits
+    int n_prims, n_nodes, n_lights;
+    unsigned int W, H;              // full image
+    int sqrt_spp, max_depth;
+    unsigned int frame;
+    int ambient;
+    unsigned int x0, y0, w, h;      // window
+    unsigned int band_h, n_ranks, rank, local_rows;
+    unsigned int tiles_x, n_tiles;
+    v3 eye, U, V, Wv, bg;
+};
+
+// ---- float3 helpers, same operation order as sutil/vec_math.h ----------------------------------------------------
+__device__ __forceinline__ v3 mk(float x, float y, float z) { return v3{x, y, z}; }
+__device__ __forceinline__ v3 vadd(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 vsub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 vmul(v3 a, v3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3 vscale(v3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ v3 vneg(v3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // vec_math.h:523-526
+__device__ __forceinline__ v3 vcross(v3 a, v3 b)                                                   // vec_math.h:529-532
+{
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float vlength(v3 v) { return sqrtf(vdot(v, v)); }  // vec_math.h:535-538
+__device__ __forceinline__ v3 vnormalize(v3 v)                               // vec_math.h:541-545
+{
+    float invLen = 1.0f / sqrtf(vdot(v, v));
+    return vscale(v, invLen);
+}
+
+// ---- RNG: cuda/random.h:30-66 -------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned int tea16(unsigned int v0, unsigned int v1)
+{
+    unsigned int s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+__device__ __forceinline__ float rnd(unsigned int& prev)
+{
+    prev = 1664525u * prev + 1013904223u;
+    return (float)(prev & 0x00FFFFFFu) / (float)0x01000000;
+}
+
+// ---- intersection programs (kernel.cu:250-416) with M^-1 hoisted to scene upload -------------------------------------
+// TransformRay (kernel.cu:125-135).  The w = 0 / w = 1 products of the 4-term operator* (Matrix.h:472-493) are
+// dropped / folded: x*1 is exact and +(m*0) can only change the sign of a zero.
+__device__ __forceinline__ v3 xf_dir(const float4 r0, const float4 r1, const float4 r2, v3 d)
+{
+    return mk(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z,
+              r2.x * d.x + r2.y * d.y + r2.z * d.z);
+}
+__device__ __forceinline__ v3 xf_point(const float4 r0, const float4 r1, const float4 r2, v3 o)
+{
+    return mk(r0.x * o.x + r0.y * o.y + r0.z * o.z + r0.w, r1.x * o.x + r1.y * o.y + r1.z * o.z + r1.w,
+              r2.x * o.x + r2.y * o.y + r2.z * o.z + r2.w);
+}
+// TransformNormal (kernel.cu:138-142): transpose(M^-1) * (n, 0)
+__device__ __forceinline__ v3 xf_normal(const float4 r0, const float4 r1, const float4 r2, v3 n)
+{
+    return mk(r0.x * n.x + r1.x * n.y + r2.x * n.z, r0.y * n.x + r1.y * n.y + r2.y * n.z,
+              r0.z * n.x + r1.z * n.y + r2.z * n.z);
+}
+
+// returns true when the program would call optixReportIntersection(t, n)
+__device__ __forceinline__ bool intersect_prim(int type, const float4 r0, const float4 r1, const float4 r2, v3 wo, v3 wd,
+                                               float& t_out, v3& n_out)
+{
+    const v3 d = xf_dir(r0, r1, r2, wd);
+    const v3 o = xf_point(r0, r1, r2, wo);
+    if (type == 2) {  // __intersection__rectangle, kernel.cu:372-416 (one-sided: only rays going down in object space)
+        const float divisor = d.y;
+        if (divisor != 0.0f) {
+            const float t = (0.0f - o.y) / divisor;
+            if (t > 0.0001f) {
+                const float px = o.x + t * d.x, pz = o.z + t * d.z;
+                const float u = px + 0.5f;      // dot(p - p0, a), a = (1,0,0), p0 = (-1/2, 0, 1/2)
+                const float v = -(pz - 0.5f);   // dot(p - p0, b), b = (0,0,-1)
+                if (0.0f < u && u < 1.0f && 0.0f < v && v < 1.0f && d.y < 0.0f) {
+                    t_out = t;
+                    n_out = xf_normal(r0, r1, r2, mk(0.0f, 1.0f, 0.0f));
+                    return true;
+                }
+            }
+        }
+        return false;
+    }
+    if (type == 3) {  // __intersection__sphere, kernel.cu:250-287 (near root only)
+        const float a = vdot(d, d);
+        const float b = 2.0f * vdot(d, o);
+        const float c = vdot(o, o) - 1.0f;
+        const float discr = b * b - 4.0f * a * c;
+        if (discr > 0.0f) {
+            const float sdiscr = sqrtf(discr);
+            const float t = (-b - sdiscr) / (2.0f * a);
+            if (t > 0.0001f) {
+                const v3 n = vnormalize(vadd(o, vscale(d, t)));
+                t_out = t;
+                n_out = xf_normal(r0, r1, r2, n);
+                return true;
+            }
+        }
+        return false;
+    }
+    if (type == 0) {  // __intersection__cylinder + GetTMinCylinder, kernel.cu:290-331, 152-181
+        const float a = d.x * d.x + d.z * d.z;
+        const float b = 2.0f * (o.x * d.x + o.z * d.z);
+        const float c = o.x * o.x + o.z * o.z - 1.0f;
+        const float discr = b * b - 4.0f * a * c;
+        if (discr > 0.001f) {
+            const float sdiscr = sqrtf(discr);
+            const float t0 = (-b + sdiscr) / (2.0f * a);
+            const float t1 = (-b - sdiscr) / (2.0f * a);
+            float t = 1e16f;
+            bool valid = false;
+            if (t0 > 0.001f) {
+                const float py = o.y + t0 * d.y;
+                if (py > -1.0f && py < 1.0f) {
+                    t = t0;
+                    valid = true;
+                }
+            }
+            if (t1 > 0.001f && t1 < t) {
+                const float py = o.y + t1 * d.y;
+                if (py > -1.0f && py < 1.0f) {
+                    t = t1;
+                    valid = true;
+                }
+            }
+            if (valid) {
+                const float px = o.x + t * d.x, pz = o.z + t * d.z;
+                t_out = t;
+                n_out = xf_normal(r0, r1, r2, mk(px, 0.0f, pz));
+                return true;
+            }
+        }
+        return false;
+    }
+    {  // __intersection__disk, kernel.cu:334-369 (two-sided, |d.y| >= 0.01)
+        const float divisor = d.y;
+        if (!(divisor > 0.0f - 0.01f && divisor < 0.0f + 0.01f)) {
+            const float t = (-o.y) / divisor;
+            if (t > 0.0001f) {
+                const v3 p = vadd(o, vscale(d, t));
+                if (vdot(p, p) < 1.0f) {
+                    t_out = t;
+                    n_out = xf_normal(r0, r1, r2, mk(0.0f, 1.0f, 0.0f));
+                    return true;
+                }
+            }
+        }
+        return false;
+    }
+}
+
+// slab test of one node box against [tmin, tmax]; identical, operation for operation, to oracle box_test()
+__device__ __forceinline__ bool box_test(const float4 q0, const float4 q1, v3 o, v3 id, float tmin, float tmax, float& tn_out)
+{
+    float t0 = (q0.x - o.x) * id.x, t1 = (q1.x - o.x) * id.x;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = (q0.y - o.y) * id.y;
+    t1 = (q1.y - o.y) * id.y;
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    t0 = (q0.z - o.z) * id.z;
+    t1 = (q1.z - o.z) * id.z;
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    tn = fmaxf(tn, tmin);
+    tf = fminf(tf, tmax);
+    tn_out = tn;
+    return tn <= tf;
+}
+
+struct Hit {
+    float t;
+    v3 n;
+    int prim;
+};
+
+// optixTrace's traversal over the LDS-resident canonical LBVH: nearest child first, far child pushed on the per-lane LDS
+// stack with its entry distance and culled against the current closest hit when popped.  A hit is accepted iff
+// tmin < t < current tmax; ties keep the lower SBT index.
+template <bool STATS>
+__device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, const float4* __restrict__ s_prims,
+                                            float2* __restrict__ s_stack, v3 o, v3 d, float tmin, float tmax, Hit& best,
+                                            unsigned int& c_nodes, unsigned int& c_tests)
+{
+    best.prim = -1;
+    best.t = tmax;
+    best.n = mk(0.0f, 0.0f, 0.0f);
+    const v3 id = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    float tn;
+    float4 q0 = s_nodes[0], q1 = s_nodes[1];
+    if (STATS) c_nodes += 1;
+    if (!box_test(q0, q1, o, id, tmin, best.t, tn)) return false;
+    int sp = 0;
+    int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
+    for (;;) {
+        bool pop = false;
+        if (right < 0) {
+            const int i = left;
+            const float4 r0 = s_prims[6 * i + 0], r1 = s_prims[6 * i + 1], r2 = s_prims[6 * i + 2];
+            const int type = __float_as_int(s_prims[6 * i + 4].w);
+            float t;
+            v3 n;
+            if (STATS) c_tests += 1;
+            if (intersect_prim(type, r0, r1, r2, o, d, t, n) && t > tmin &&
+                (t < best.t || (t == best.t && best.prim >= 0 && i < best.prim))) {
+                best.t = t;
+                best.n = n;
+                best.prim = i;
+            }
+            pop = true;
+        } else {
+            const float4 l0 = s_nodes[2 * left], l1 = s_nodes[2 * left + 1];
+            const float4 h0 = s_nodes[2 * right], h1 = s_nodes[2 * right + 1];
+            float tl, tr;
+            if (STATS) c_nodes += 2;
+            const bool hl = box_test(l0, l1, o, id, tmin, best.t, tl);
+            const bool hr = box_test(h0, h1, o, id, tmin, best.t, tr);
+            if (hl && hr) {
+                const bool swap = tr < tl;
+                // push the far child
+                const int far_idx = swap ? left : right;
+                const float far_t = swap ? tl : tr;
+                s_stack[sp * kBlock] = make_float2(far_t, __int_as_float(far_idx));
+                ++sp;
+                if (swap) {
+                    left = __float_as_int(h0.w);
+                    right = __float_as_int(h1.w);
+                } else {
+                    left = __float_as_int(l0.w);
+                    right = __float_as_int(l1.w);
+                }
+            } else if (hl) {
+                left = __float_as_int(l0.w);
+                right = __float_as_int(l1.w);
+            } else if (hr) {
+                left = __float_as_int(h0.w);
+                right = __float_as_int(h1.w);
+            } else {
+                pop = true;
+            }
+        }
+        if (pop) {
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                const float2 e = s_stack[sp * kBlock];
+                if (e.x <= best.t) {
+                    const int idx = __float_as_int(e.y);
+                    const float4 n0 = s_nodes[2 * idx], n1 = s_nodes[2 * idx + 1];
+                    left = __float_as_int(n0.w);
+                    right = __float_as_int(n1.w);
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) break;
+        }
+    }
+    return best.prim >= 0;
+}
+
+// GetRayOnHemisphere, kernel.cu:101-122
+__device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed)
+{
+    v3 ray;
+    const v3 Y = vnormalize(direction);
+    const v3 X = vnormalize(mk(Y.y - Y.z, -Y.x, Y.x));
+    const v3 Z = vcross(Y, X);
+    const float expo = 1.f / (coefficient + 1.f);
+    do {
+        const float r1 = rnd(seed);
+        const float r2 = rnd(seed);
+        const float phi = 2.f * kPi * r1;
+        const float base = 1.f - r2;
+        // powf(x, 1) == x exactly in a correctly rounded libm; keep that exact on the device too
+        const float theta = acosf(expo == 1.0f ? base : powf(base, expo));
+        float st, ct, sp, cp;
+        st = sinf(theta);
+        ct = cosf(theta);
+        sp = sinf(phi);
+        cp = cosf(phi);
+        ray = vsub(vadd(vscale(X, st * cp), vscale(Y, ct)), vscale(Z, st * sp));
+    } while (vdot(normal, ray) < 0.f);
+    return ray;
+}
+
+__device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }  // vec_math.h:115-118
+
+__device__ __forceinline__ unsigned int wave_sum(unsigned int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// =====================================================================================================================
+// The render megakernel.  One wave = one 16x4 pixel tile pulled from a global queue (persistent workgroups); one lane =
+// one pixel.  Each loop iteration traces exactly ONE ray per live lane (primary, bounce or shadow), so lanes at different
+// depths / samples share the same traversal code; a lane whose path ends regenerates its next sample in place, which
+// keeps the sample sum in the reference's order (kernel.cu:206-236).
+// PATH = Params::enablePathTracing.  STATS adds the V/T/h counters used for the roofline's algorithmic bytes.
+// =====================================================================================================================
+template <bool PATH, bool STATS>
+__global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4* s_nodes = reinterpret_cast<float4*>(smem);
+    float4* s_prims = s_nodes + 2 * p.n_nodes;
+    float2* s_stack_base = reinterpret_cast<float2*>(s_prims + 6 * p.n_prims);
+    LightRec* s_lights = reinterpret_cast<LightRec*>(s_stack_base + kStackDepth * kBlock);
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.nodes[i];
+    for (int i = tid; i < 6 * p.n_prims; i += kBlock) s_prims[i] = p.prims[i];
+    {
+        const float* src = reinterpret_cast<const float*>(p.lights);
+        float* dst = reinterpret_cast<float*>(s_lights);
+        for (int i = tid; i < p.n_lights * 16; i += kBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    float2* s_stack = s_stack_base + tid;
+    const int lane = tid & 63;
+    const unsigned int nn = (unsigned int)(p.sqrt_spp * p.sqrt_spp);
+    const float inc = 1.0f / (float)p.sqrt_spp;
+    const float dimX = (float)p.W, dimY = (float)p.H;
+
+    unsigned int c_rays = 0, c_occl = 0, c_nodes = 0, c_tests = 0, c_hits = 0;
+
+    for (;;) {
+        unsigned int tile = 0;
+        if (lane == 0) tile = atomicAdd(p.queue, 1u);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= p.n_tiles) break;
+
+        const unsigned int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+        const unsigned int lx = tx * kTileW + (lane & (kTileW - 1));
+        const unsigned int lr = ty * kTileH + (lane >> 4);  // local (compact) row
+        const bool in_range = lx < p.w && lr < p.local_rows;
+        // local row -> window row under the band interleave
+        const unsigned int band = lr / p.band_h;
+        const unsigned int wrow = (band * p.n_ranks + p.rank) * p.band_h + (lr - band * p.band_h);
+        const unsigned int gx = p.x0 + lx, gy = p.y0 + wrow;
+        const float fx = (float)gx, fy = (float)gy;
+
+        // __raygen__rg state (kernel.cu:184-247)
+        unsigned int pix_seed = tea16(p.W * gy + gx, p.frame);
+        v3 color = mk(0.0f, 0.0f, 0.0f);
+        unsigned int s = 0;            // next sample to start
+        bool alive = in_range;         // lane still has samples to finish
+        bool in_path = false;
+        int depth = 0;
+        int phase = 0;                 // distributed mode: 0 = radiance ray in flight, 1 = shadow ray in flight
+        unsigned int seed = 0;
+        v3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
+        float tmin = 0.0f, tmax = 0.0f;
+        // per-level records, folded innermost-first when the path ends
+        v3 lvA[kMaxLevels];            // PATH: w_k = dot(N,Ra)*kd ; distributed: a_k = falloff*diffuse
+        int lvPrim[kMaxLevels];        // distributed: primitive of level k (kr, kd re-read at fold time)
+#pragma unroll
+        for (int k = 0; k < kMaxLevels; ++k) {
+            lvA[k] = mk(0, 0, 0);
+            lvPrim[k] = 0;
+        }
+        // distributed: state kept across the shadow ray
+        v3 sN = mk(0, 0, 0), sRr = mk(0, 0, 0);
+        float sDist = 0.0f;
+        int sPrim = 0, sLight = 0;
+        bool sNVneg = false;
+
+        while (__ballot(alive) != 0ull) {
+            if (alive && !in_path) {
+                // start sample s: kernel.cu:206-231.  i-major order, x jitter drawn first
+                const unsigned int i = s / (unsigned int)p.sqrt_spp, j = s - i * (unsigned int)p.sqrt_spp;
+                const float r0 = rnd(pix_seed);
+                const float r1 = rnd(pix_seed);
+                const float dx = 2.0f * ((fx + ((float)i + r0) * inc) / dimX) - 1.0f;
+                const float dy = 2.0f * ((fy + ((float)j + r1) * inc) / dimY) - 1.0f;
+                ro = p.eye;
+                rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.Wv));
+                tmin = 0.05f;
+                tmax = 1e16f;
+                depth = 0;
+                phase = 0;
+                seed = pix_seed;
+                in_path = true;
+                ++s;
+            }
+            if (alive) {
+                Hit h;
+                c_rays += 1;
+                const bool hit = closest_hit<STATS>(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h, c_nodes, c_tests);
+                if (STATS && hit) c_hits += 1;
+
+                bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
+                v3 term = mk(0, 0, 0);
+
+                if (PATH) {
+                    if (!hit) {
+                        term = p.bg;  // __miss__ms, kernel.cu:419-423
+                        done = true;
+                    } else {
+                        // __closesthit__ch, path branch: kernel.cu:426-475
+                        const float4 m3 = s_prims[6 * h.prim + 3], m5 = s_prims[6 * h.prim + 5];
+                        v3 N = vnormalize(h.n);
+                        const float t = h.t;
+                        const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
+                        const v3 x = vadd(ro, vscale(vnormalize(rd), t));
+                        const v3 V = vnormalize(vsub(ro, x));
+                        if (vdot(N, V) < 0.0f) N = vscale(N, -1.0f);
+                        if (m5.x > 0.01f) {
+                            term = mk(m5.x, m5.y, m5.z);
+                            done = true;
+                        } else if (depth < p.max_depth) {
+                            const v3 Ra = hemisphere(N, N, 0.0f, seed);
+                            const v3 wk = vadd(mk(0.0f, 0.0f, 0.0f), vscale(mk(m3.x, m3.y, m3.z), vdot(N, Ra)));
+#pragma unroll
+                            for (int k = 0; k < kMaxLevels; ++k)
+                                if (k == depth) lvA[k] = wk;
+                            ++depth;
+                            ro = x;
+                            rd = Ra;
+                            tmin = rayEpsilon;
+                            tmax = 1e6f;
+                        } else {
+                            term = mk(0.0f, 0.0f, 0.0f);
+                            done = true;
+                        }
+                    }
+                } else {
+                    if (phase == 1) {
+                        // back from the shadow ray: kernel.cu:498-535 (+ __closesthit__full_occlusion :539-549)
+                        c_occl += 1;
+                        v3 illum = mk(1.0f, 1.0f, 1.0f);  // occlusion miss leaves the payload untouched
+                        if (hit) {
+                            const float4 b5 = s_prims[6 * h.prim + 5];
+                            illum = mk(fminf(b5.x, 1.0f), fminf(b5.y, 1.0f), fminf(b5.z, 1.0f));
+                        }
+                        const LightRec& L = s_lights[sLight];
+                        const float4 m3 = s_prims[6 * sPrim + 3];
+                        const v3 kd = mk(m3.x, m3.y, m3.z);
+                        const float spec = m3.w;
+                        const v3 Lm = rd;
+                        const v3 lightNormal = mk(L.normal[0], L.normal[1], L.normal[2]);
+                        const v3 lightColor = vscale(illum, fabsf(vdot(Lm, lightNormal)));
+                        const float falloff = 1.0f / (1.0f + L.falloff * sDist);
+                        const v3 compDiffuse =
+                            sNVneg ? mk(0.0f, 0.0f, 0.0f) : vmul(vscale(lightColor, fmaxf(vdot(sN, Lm), 0.0f)), kd);
+                        const v3 a = vadd(mk(0.0f, 0.0f, 0.0f), vscale(compDiffuse, falloff));
+                        bool bounce = false;
+                        v3 r = mk(0, 0, 0);
+                        if (depth < p.max_depth) {
+                            if (p.ambient) {
+                                if (spec > 0.5f) {
+                                    r = hemisphere(sN, sRr, spec, seed);
+                                    bounce = true;
+                                }
+                            } else {
+                                r = spec < 0.5f ? hemisphere(sN, sN, 0.0f, seed) : hemisphere(sN, sRr, spec, seed);
+                                bounce = true;
+                            }
+                        }
+                        if (bounce) {
+#pragma unroll
+                            for (int k = 0; k < kMaxLevels; ++k)
+                                if (k == depth) {
+                                    lvA[k] = a;
+                                    lvPrim[k] = sPrim;
+                                }
+                            ++depth;
+                            rd = r;            // ro = x and tmin = rayEpsilon are still those of the shadow ray
+                            tmax = 1e6f;
+                            phase = 0;
+                        } else {
+                            term = a;
+                            if (p.ambient && depth < p.max_depth) term = vadd(term, vmul(kd, mk(0.1f, 0.1f, 0.1f)));
+                            done = true;
+                        }
+                    } else if (!hit) {
+                        term = p.bg;
+                        done = true;
+                    } else {
+                        // __closesthit__ch, distributed branch up to the shadow trace: kernel.cu:426-455, 477-499
+                        const float4 m5 = s_prims[6 * h.prim + 5];
+                        v3 N = vnormalize(h.n);
+                        const float t = h.t;
+                        const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
+                        const v3 dn = vnormalize(rd);
+                        const v3 x = vadd(ro, vscale(dn, t));
+                        const v3 V = vnormalize(vsub(ro, x));
+                        if (vdot(N, V) < 0.0f) N = vscale(N, -1.0f);
+                        if (vlength(mk(m5.x, m5.y, m5.z)) > 0.01f) {
+                            term = mk(1.0f, 1.0f, 1.0f);
+                            done = true;
+                        } else {
+                            const int l = (int)(rnd(seed) * (float)(p.n_lights - 1));
+                            const LightRec& L = s_lights[l];
+                            const float ra = rnd(seed);  // Q1: v1 factor first
+                            const float rb = rnd(seed);
+                            const v3 samplingPos =
+                                vadd(vadd(mk(L.corner[0], L.corner[1], L.corner[2]), vscale(mk(L.v1[0], L.v1[1], L.v1[2]), ra)),
+                                     vscale(mk(L.v2[0], L.v2[1], L.v2[2]), rb));
+                            const v3 toL = vsub(samplingPos, x);
+                            const v3 Lm = vnormalize(toL);
+                            const float lightDistance = vlength(toL);
+                            const v3 omega = vneg(dn);
+                            sRr = vadd(vneg(omega), vscale(N, 2.0f * vdot(N, omega)));
+                            sN = N;
+                            sNVneg = vdot(N, V) < 0.f;
+                            sDist = lightDistance;
+                            sPrim = h.prim;
+                            sLight = l;
+                            ro = x;
+                            rd = Lm;
+                            tmin = rayEpsilon;
+                            tmax = lightDistance - rayEpsilon;
+                            phase = 1;
+                        }
+                    }
+                }
+
+                if (done) {
+                    // fold the level records innermost-first: kernel.cu:471-472 (path), :504,519,531 (distributed)
+#pragma unroll
+                    for (int k = kMaxLevels - 1; k >= 0; --k) {
+                        if (k < depth) {
+                            if (PATH) {
+                                term = vmul(lvA[k], term);
+                            } else {
+                                const float4 m3 = s_prims[6 * lvPrim[k] + 3], m4 = s_prims[6 * lvPrim[k] + 4];
+                                term = vadd(lvA[k], vmul(mk(m4.x, m4.y, m4.z), term));
+                                if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
+                            }
+                        }
+                    }
+                    color = vadd(color, term);
+                    in_path = false;
+                    if (s == nn) alive = false;
+                }
+            }
+        }
+
+        if (in_range) {
+            // kernel.cu:236-246.  float3 / float multiplies by the reciprocal (vec_math.h:479-483)
+            v3 cur = vscale(color, 1.0f / (float)nn);
+            const size_t idx = (size_t)lr * p.w + lx;
+            if (p.frame > 0) {
+                const float4 prev4 = p.accum[idx];
+                const v3 prev = mk(prev4.x, prev4.y, prev4.z);
+                const float ratio = 1.0f / (float)(p.frame + 1);
+                cur = vadd(prev, vscale(vsub(cur, prev), ratio));  // lerp, vec_math.h:496-499
+            }
+            p.accum[idx] = make_float4(cur.x, cur.y, cur.z, 1.0f);
+            // make_color, kernel.cu:90-98
+            p.image[idx] = make_uchar4((unsigned char)(clampf(cur.x, 0.0f, 1.0f) * 255.0f),
+                                       (unsigned char)(clampf(cur.y, 0.0f, 1.0f) * 255.0f),
+                                       (unsigned char)(clampf(cur.z, 0.0f, 1.0f) * 255.0f), 255u);
+        }
+    }
+
+    // one atomic per wave per counter
+    c_rays = wave_sum(c_rays);
+    c_occl = wave_sum(c_occl);
+    if (STATS) {
+        c_nodes = wave_sum(c_nodes);
+        c_tests = wave_sum(c_tests);
+        c_hits = wave_sum(c_hits);
+    }
+    if (lane == 0) {
+        atomicAdd(&p.counters[0], (unsigned long long)c_rays);
+        if (!PATH) atomicAdd(&p.counters[1], (unsigned long long)c_occl);
+        if (STATS) {
+            atomicAdd(&p.counters[2], (unsigned long long)c_nodes);
+            atomicAdd(&p.counters[3], (unsigned long long)c_tests);
+            atomicAdd(&p.counters[4], (unsigned long long)c_hits);
+        }
+    }
+}
+
+// =====================================================================================================================
+// Scene preparation + canonical LBVH build, one workgroup (n <= 512): replaces optixAccelBuild (renderer.cpp:514-611) and
+// hoists Matrix4x4::inverse() (Matrix.h:591-635) out of the intersection programs.
+// =====================================================================================================================
+struct PrimIn {  // = rtgo_prim
+    unsigned int type;
+    float M[16];
+    float kd[3], kr[3], spec, Le[3];
+};
+
+__device__ __forceinline__ float det4(const float* m)
+{
+    // Matrix.h:591-608, term order and product association preserved
+    return m[0] * m[5] * m[10] * m[15] - m[0] * m[5] * m[11] * m[14] + m[0] * m[9] * m[14] * m[7] - m[0] * m[9] * m[6] * m[15] +
+           m[0] * m[13] * m[6] * m[11] - m[0] * m[13] * m[10] * m[7] - m[4] * m[1] * m[10] * m[15] + m[4] * m[1] * m[11] * m[14] -
+           m[4] * m[9] * m[14] * m[3] + m[4] * m[9] * m[2] * m[15] - m[4] * m[13] * m[2] * m[11] + m[4] * m[13] * m[10] * m[3] +
+           m[8] * m[1] * m[6] * m[15] - m[8] * m[1] * m[14] * m[7] + m[8] * m[5] * m[14] * m[3] - m[8] * m[5] * m[2] * m[15] +
+           m[8] * m[13] * m[2] * m[7] - m[8] * m[13] * m[6] * m[3] - m[12] * m[1] * m[6] * m[11] + m[12] * m[1] * m[10] * m[7] -
+           m[12] * m[5] * m[10] * m[3] + m[12] * m[5] * m[2] * m[11] - m[12] * m[9] * m[2] * m[7] + m[12] * m[9] * m[6] * m[3];
+}
+
+// one cofactor group of Matrix.h:612-635: a*(b*c - d*e)
+#define RTGO_G(a, b, c, d, e) (m[a] * (m[b] * m[c] - m[d] * m[e]))
+
+__device__ __forceinline__ void inverse_rows012(const float* m, float* o)
+{
+    const float d = 1.0f / det4(m);
+    o[0] = d * (RTGO_G(5, 10, 15, 14, 11) + RTGO_G(9, 14, 7, 6, 15) + RTGO_G(13, 6, 11, 10, 7));
+    o[4] = d * (RTGO_G(6, 8, 15, 12, 11) + RTGO_G(10, 12, 7, 4, 15) + RTGO_G(14, 4, 11, 8, 7));
+    o[8] = d * (RTGO_G(7, 8, 13, 12, 9) + RTGO_G(11, 12, 5, 4, 13) + RTGO_G(15, 4, 9, 8, 5));
+    o[1] = d * (RTGO_G(9, 2, 15, 14, 3) + RTGO_G(13, 10, 3, 2, 11) + RTGO_G(1, 14, 11, 10, 15));
+    o[5] = d * (RTGO_G(10, 0, 15, 12, 3) + RTGO_G(14, 8, 3, 0, 11) + RTGO_G(2, 12, 11, 8, 15));
+    o[9] = d * (RTGO_G(11, 0, 13, 12, 1) + RTGO_G(15, 8, 1, 0, 9) + RTGO_G(3, 12, 9, 8, 13));
+    o[2] = d * (RTGO_G(13, 2, 7, 6, 3) + RTGO_G(1, 6, 15, 14, 7) + RTGO_G(5, 14, 3, 2, 15));
+    o[6] = d * (RTGO_G(14, 0, 7, 4, 3) + RTGO_G(2, 4, 15, 12, 7) + RTGO_G(6, 12, 3, 0, 15));
+    o[10] = d * (RTGO_G(15, 0, 5, 4, 1) + RTGO_G(3, 4, 13, 12, 5) + RTGO_G(7, 12, 1, 0, 13));
+    o[3] = d * (RTGO_G(1, 10, 7, 6, 11) + RTGO_G(5, 2, 11, 10, 3) + RTGO_G(9, 6, 3, 2, 7));
+    o[7] = d * (RTGO_G(2, 8, 7, 4, 11) + RTGO_G(6, 0, 11, 8, 3) + RTGO_G(10, 4, 3, 0, 7));
+    o[11] = d * (RTGO_G(3, 8, 5, 4, 9) + RTGO_G(7, 0, 9, 8, 1) + RTGO_G(11, 4, 1, 0, 5));
+}
+#undef RTGO_G
+
+// Primitive::GetAabb / CubeBox::TransformAndAlign (primitive.cpp:35-79, 100-115): the 8 corners of [-1,1]^3 through the
+// 4-term matrix product (sum seeded with 0.0f, Matrix.h:344-360), min/max seeded with +-50, +-1e-3 pad.
+__device__ __forceinline__ void cube_aabb(const float* M, float* bb)
+{
+    float mn[3] = {50.0f, 50.0f, 50.0f}, mx[3] = {-50.0f, -50.0f, -50.0f};
+    // corner order of CubeBox::face0/face1 columns: x = {-1,-1,1,1}, z = {-1,1,-1,1}, y = -1 (face0) / +1 (face1)
+    const float cxs[4] = {-1.f, -1.f, 1.f, 1.f}, czs[4] = {-1.f, 1.f, -1.f, 1.f};
+    for (int i = 0; i < 4; ++i)
+        for (int a = 0; a < 3; ++a) {
+            const float* r = M + 4 * a;
+            float p0 = 0.0f, p1 = 0.0f;
+            p0 += r[0] * cxs[i];
+            p0 += r[1] * -1.f;
+            p0 += r[2] * czs[i];
+            p0 += r[3] * 1.f;
+            p1 += r[0] * cxs[i];
+            p1 += r[1] * 1.f;
+            p1 += r[2] * czs[i];
+            p1 += r[3] * 1.f;
+            float t = (p0 < mn[a]) ? p0 : mn[a];
+            mn[a] = (p1 < t) ? p1 : t;
+            t = (mx[a] < p0) ? p0 : mx[a];
+            mx[a] = (t < p1) ? p1 : t;
+        }
+    for (int a = 0; a < 3; ++a) {
+        bb[a] = mn[a] - 0.001f;
+        bb[3 + a] = mx[a] + 0.001f;
+    }
+}
+
+__device__ __forceinline__ unsigned int expand_bits(unsigned int v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n, int i, int j)
+{
+    if (j < 0 || j >= n) return -1;
+    const unsigned int a = (unsigned int)(keys[i] >> 32), b = (unsigned int)(keys[j] >> 32);
+    if (a == b) return 32 + __clz((unsigned int)i ^ (unsigned int)j);
+    return __clz(a ^ b);
+}
+
+// out_nodes: (2n-1) x 2 float4; out_prims: n x 6 float4; aabb_io: n x 6 floats (read when have_aabb, else written);
+// out_meta[0] = tree depth (levels below the root that a traversal stack may need)
+__global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
+                                                          int have_aabb, int n, float4* __restrict__ out_nodes,
+                                                          float4* __restrict__ out_prims, int* __restrict__ out_meta)
+{
+    __shared__ float s_box[kMaxPrims][6];
+    __shared__ unsigned long long s_keys[kMaxPrims];
+    __shared__ float s_nbox[2 * kMaxPrims][6];
+    __shared__ int s_left[kMaxPrims], s_right[kMaxPrims];
+    __shared__ int s_parent[2 * kMaxPrims];
+    __shared__ int s_visit[kMaxPrims];
+    __shared__ float s_red[6][kMaxPrims];
+    __shared__ int s_depth;
+
+    const int i = threadIdx.x;
+    if (i == 0) s_depth = 0;
+    // ---- per primitive: inverse, record, AABB
+    if (i < n) {
+        const PrimIn P = prims[i];
+        float inv[12];
+        inverse_rows012(P.M, inv);
+        out_prims[6 * i + 0] = make_float4(inv[0], inv[1], inv[2], inv[3]);
+        out_prims[6 * i + 1] = make_float4(inv[4], inv[5], inv[6], inv[7]);
+        out_prims[6 * i + 2] = make_float4(inv[8], inv[9], inv[10], inv[11]);
+        out_prims[6 * i + 3] = make_float4(P.kd[0], P.kd[1], P.kd[2], P.spec);
+        out_prims[6 * i + 4] = make_float4(P.kr[0], P.kr[1], P.kr[2], __int_as_float((int)P.type));
+        out_prims[6 * i + 5] = make_float4(P.Le[0], P.Le[1], P.Le[2], 0.0f);
+        float bb[6];
+        if (have_aabb) {
+            for (int a = 0; a < 6; ++a) bb[a] = aabb_io[6 * i + a];
+        } else {
+            cube_aabb(P.M, bb);
+            for (int a = 0; a < 6; ++a) aabb_io[6 * i + a] = bb[a];
+        }
+        for (int a = 0; a < 6; ++a) s_box[i][a] = bb[a];
+    }
+    // ---- scene bounds (min/max are exact: any reduction order gives the same value)
+    for (int a = 0; a < 3; ++a) {
+        s_red[a][i] = (i < n) ? s_box[i][a] : INFINITY;
+        s_red[3 + a][i] = (i < n) ? s_box[i][3 + a] : -INFINITY;
+    }
+    __syncthreads();
+    for (int stride = kMaxPrims / 2; stride > 0; stride >>= 1) {
+        if (i < stride)
+            for (int a = 0; a < 3; ++a) {
+                s_red[a][i] = fminf(s_red[a][i], s_red[a][i + stride]);
+                s_red[3 + a][i] = fmaxf(s_red[3 + a][i], s_red[3 + a][i + stride]);
+            }
+        __syncthreads();
+    }
+    // ---- Morton keys: (30-bit code << 32) | primitive index; padding keys sort last
+    {
+        unsigned long long key = ~0ull;
+        if (i < n) {
+            unsigned int q[3];
+            for (int a = 0; a < 3; ++a) {
+                const float c = (s_box[i][a] + s_box[i][3 + a]) * 0.5f;
+                const float ext = s_red[3 + a][0] - s_red[a][0];
+                const float u = ext > 0.0f ? (c - s_red[a][0]) / ext : 0.0f;
+                q[a] = (unsigned int)fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+            }
+            const unsigned int code = (expand_bits(q[0]) << 2) | (expand_bits(q[1]) << 1) | expand_bits(q[2]);
+            key = ((unsigned long long)code << 32) | (unsigned int)i;
+        }
+        s_keys[i] = key;
+    }
+    __syncthreads();
+    // ---- bitonic sort of kMaxPrims keys in LDS (keys are unique, so the order is the (code, index) order)
+    for (int k = 2; k <= kMaxPrims; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+                const unsigned long long a = s_keys[i], b = s_keys[ixj];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) {
+                    s_keys[i] = b;
+                    s_keys[ixj] = a;
+                }
+            }
+            __syncthreads();
+        }
+    // ---- leaves
+    const int leaf0 = n - 1;
+    if (i < n) {
+        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+        for (int a = 0; a < 6; ++a) s_nbox[leaf0 + i][a] = s_box[prim][a];
+    }
+    if (i < 2 * n - 1) s_parent[i] = -1;
+    if (i + kMaxPrims < 2 * n - 1) s_parent[i + kMaxPrims] = -1;
+    if (i < n) s_visit[i] = 0;
+    __syncthreads();
+    // ---- Karras 2012 internal nodes
+    if (i < n - 1) {
+        const int d = (lbvh_delta(s_keys, n, i, i + 1) - lbvh_delta(s_keys, n, i, i - 1)) >= 0 ? 1 : -1;
+        const int dmin = lbvh_delta(s_keys, n, i, i - d);
+        int lmax = 2;
+        while (lbvh_delta(s_keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (lbvh_delta(s_keys, n, i, i + (l + t) * d) > dmin) l += t;
+        const int j = i + l * d;
+        const int dnode = lbvh_delta(s_keys, n, i, j);
+        int s = 0, t = l;
+        do {
+            t = (t + 1) / 2;
+            if (lbvh_delta(s_keys, n, i, i + (s + t) * d) > dnode) s += t;
+        } while (t > 1);
+        const int gamma = i + s * d + (d < 0 ? -1 : 0);
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int left = (lo == gamma) ? leaf0 + gamma : gamma;
+        const int right = (hi == gamma + 1) ? leaf0 + gamma + 1 : gamma + 1;
+        s_left[i] = left;
+        s_right[i] = right;
+        s_parent[left] = i;
+        s_parent[right] = i;
+    }
+    __syncthreads();
+    // ---- bottom-up box fit; the second arrival at a node (LDS atomic) owns it
+    if (i < n && n > 1) {
+        int pnode = s_parent[leaf0 + i];
+        int levels = 1;
+        while (pnode >= 0) {
+            __threadfence_block();
+            if (atomicAdd(&s_visit[pnode], 1) == 0) break;
+            __threadfence_block();
+            const int L = s_left[pnode], R = s_right[pnode];
+            for (int a = 0; a < 3; ++a) {
+                s_nbox[pnode][a] = fminf(s_nbox[L][a], s_nbox[R][a]);
+                s_nbox[pnode][3 + a] = fmaxf(s_nbox[L][3 + a], s_nbox[R][3 + a]);
+            }
+            pnode = s_parent[pnode];
+            ++levels;
+        }
+        (void)levels;
+    }
+    __syncthreads();
+    // ---- depth of every leaf (stack bound) and write-out
+    if (i < n) {
+        int dep = 0;
+        int q = s_parent[leaf0 + i];
+        while (q >= 0) {
+            ++dep;
+            q = s_parent[q];
+        }
+        atomicMax(&s_depth, dep);
+    }
+    for (int k = i; k < 2 * n - 1; k += kMaxPrims) {
+        int left, right;
+        if (k >= leaf0) {
+            left = (int)(s_keys[k - leaf0] & 0xFFFFFFFFu);
+            right = -1;
+        } else {
+            left = s_left[k];
+            right = s_right[k];
+        }
+        out_nodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(left));
+        out_nodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(right));
+    }
+    __syncthreads();
+    if (i == 0) out_meta[0] = s_depth;
+}
+
+}  // namespace rtgo

@@ -1,0 +1,114 @@
+// capi_host.cpp -- the C view of the host surface declared in include/rtgo_host.h.
+#include <rtgo_host.h>
+
+#include "renderer.h"
+
+#include <cstring>
+#include <string>
+
+using namespace engine::host;
+
+namespace {
+std::string g_error;
+
+bool scene_from_name(const std::string& s, SceneModel& out)
+{
+    // the --scene table of engine/main.cpp:104-143
+    if (s == "plateau") out = SceneModel::PLATE;
+    else if (s == "cornell") out = SceneModel::CORNELL;
+    else if (s == "slide") out = SceneModel::SLIDE;
+    else if (s == "window") out = SceneModel::WINDOW;
+    else if (s == "balls") out = SceneModel::BALLS;
+    else if (s == "checkered") out = SceneModel::CHECKERED;
+    else if (s == "mirror_spheres") out = SceneModel::MIRROR_SPHERES;
+    else if (s == "soft_mirrors") out = SceneModel::SOFT_MIRRORS;
+    else return false;
+    return true;
+}
+}  // namespace
+
+extern "C" {
+
+const char* rtgo_host_last_error(void) { return g_error.c_str(); }
+
+int rtgo_host_scene_build(const char* scene_name, uint32_t width, uint32_t height, rtgo_host_scene* out)
+{
+    SceneModel model;
+    if (!scene_name || !out || width == 0 || height == 0 || !scene_from_name(scene_name, model)) {
+        g_error = "rtgo_host_scene_build: bad argument or unknown scene";
+        return RTGO_E_INVALID;
+    }
+    std::memset(out, 0, sizeof *out);
+    Scene scene(model, width, height);
+    uint32_t n = 0;
+    for (const std::shared_ptr<Shape>& shape : scene.GetShapes())
+        for (const Primitive& p : shape->GetPrimitives()) {
+            if (n >= RTGO_MAX_PRIMS) {
+                g_error = "rtgo_host_scene_build: too many primitives";
+                return RTGO_E_UNSUPPORTED;
+            }
+            p.CopyToDevice(out->prims[n]);
+            out->aabbs[n] = p.GetAabb();
+            ++n;
+        }
+    out->n_prims = n;
+    uint32_t nl = 0;
+    for (const SurfaceLight& l : scene.GetSurfaceLights()) {
+        if (nl >= RTGO_MAX_LIGHTS) break;
+        rtgo_light& r = out->lights[nl++];
+        const glm::vec3 c = l.GetCorner(), v1 = l.GetV1(), v2 = l.GetV2(), nn = l.GetNormal(), col = l.GetColor();
+        const float vals[15] = {c.x, c.y, c.z, v1.x, v1.y, v1.z, v2.x, v2.y, v2.z, nn.x, nn.y, nn.z, col.x, col.y, col.z};
+        std::memcpy(r.corner, vals, sizeof vals);
+        r.falloff = l.GetFalloff();
+    }
+    out->n_lights = nl;
+    float3 u, v, w;
+    scene.GetCamera()->UVWFrame(u, v, w);
+    const float3 e = scene.GetCamera()->eye();
+    const float cam[12] = {e.x, e.y, e.z, u.x, u.y, u.z, v.x, v.y, v.z, w.x, w.y, w.z};
+    std::memcpy(out->eye, cam, sizeof cam);
+    const glm::vec3 bg = scene.GetBackgroundColor();
+    out->background[0] = bg.r;
+    out->background[1] = bg.g;
+    out->background[2] = bg.b;
+    return RTGO_OK;
+}
+
+int rtgo_host_render(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient, int frames,
+                     int device, void* host_image, void* host_accum, rtgo_stats* stats)
+{
+    SceneModel model;
+    if (!scene_name || !mode || !scene_from_name(scene_name, model) || width == 0 || height == 0 || sample < 1 || frames < 1) {
+        g_error = "rtgo_host_render: bad argument";
+        return RTGO_E_INVALID;
+    }
+    RenderMode rm;
+    if (std::string(mode) == "path") rm = RenderMode::PATH_TRACING;
+    else if (std::string(mode) == "distributed") rm = RenderMode::DISTRIBUTED_RAY_TRACING;
+    else {
+        g_error = "rtgo_host_render: mode must be path or distributed";
+        return RTGO_E_INVALID;
+    }
+    try {
+        auto scene = std::make_shared<Scene>(model, width, height);
+        Renderer renderer(scene, rm, sample, ambient != 0);
+        renderer.SetDevice(device);
+        renderer.SetFrames(frames);
+        renderer.Display();
+        if (host_image) {
+            const std::vector<unsigned char> img = renderer.ReadImage();
+            std::memcpy(host_image, img.data(), img.size());
+        }
+        if (host_accum) {
+            const std::vector<float> acc = renderer.ReadAccum();
+            std::memcpy(host_accum, acc.data(), acc.size() * sizeof(float));
+        }
+        if (stats) *stats = renderer.Stats();
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return RTGO_E_STATE;
+    }
+    return RTGO_OK;
+}
+
+}  // extern "C"

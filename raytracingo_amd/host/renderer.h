@@ -1,0 +1,64 @@
+// renderer.h -- engine::host::Renderer (engine/renderer.h:55-231) over the rtgo C ABI instead of the OptiX host API.
+// Same constructor and Display() entry point; since the MI355X box has no display stack, Display() runs a fixed number
+// of progressive frames headlessly (the reference's Update/LaunchFrame loop, renderer.cpp:841-862, without GLFW) and
+// can write the Ctrl+S image (renderer.cpp:684-695).
+#pragma once
+#include "scene.h"
+#include <rtgo.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace engine {
+namespace host {
+enum class RenderMode { DISTRIBUTED_RAY_TRACING, PATH_TRACING };
+
+class Renderer {
+public:
+    /// \param sqrtSamplePerPixel N: N x N stratified samples per pixel per frame (--sample)
+    Renderer(std::shared_ptr<Scene> scene, RenderMode renderMode, int sqrtSamplePerPixel, bool useAmbientCoeff);
+    ~Renderer();
+    Renderer(const Renderer&) = delete;
+    Renderer& operator=(const Renderer&) = delete;
+
+    /// Run the frame loop: frames 0..m_frames-1 accumulate into the running average; then save if an output is set.
+    void Display();
+
+    // ---- headless controls (no reference counterpart: the reference is interactive only) ----
+    void SetFrames(int frames) { m_frames = frames; }
+    void SetOutputFile(const std::string& path) { m_outputFile = path; }
+    void SetDevice(int device) { m_device = device; }
+    /// render exactly one more frame (frameCount advances like Renderer::Update does)
+    void RenderFrame();
+    /// the 8-bit image (uchar4, row 0 = bottom row) and the float accumulation buffer of the last frame
+    std::vector<unsigned char> ReadImage();
+    std::vector<float> ReadAccum();
+    rtgo_stats Stats();
+    /// P6 file, rows flipped so that the top row comes first, alpha dropped (sutil.cpp:81-101, 377-388)
+    static void SavePPM(const std::string& path, const unsigned char* rgba, unsigned int width, unsigned int height);
+
+private:
+    std::shared_ptr<Scene> m_scene;
+    RenderMode m_renderMode;
+    bool m_useAmbientCoefficient;
+    int m_sqrtSamplePerPixel;
+    rtgo_ctx* m_context;
+    rtgo_frame m_params;   // the launch constants the reference keeps in device::Params
+    bool m_firstLaunch;
+    int m_frames;
+    int m_device;
+    std::string m_outputFile;
+
+    void Initialize();
+    void CreateContext();
+    void CreateRayGen();
+    void CreateMiss();
+    void CreateShapes();
+    void WriteLights();
+    void Update();
+    void LaunchFrame();
+    void CleanUp();
+    void Check(int rc, const char* what) const;
+};
+}  // namespace host
+}  // namespace engine

@@ -1,0 +1,78 @@
+"""Scene tables from the PRODUCT host code (librtgo_host.so: engine::host::Scene and friends, C++).
+
+Returns the flattened inputs of the hot path -- what Renderer::CreateShapes / CreateRayGen / CreateMiss / WriteLights
+pass to the C ABI -- as numpy arrays, for the Python drivers (bench.py, the band driver).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+
+LIB_PATH = os.path.join(capi.PKG_DIR, "librtgo_host.so")
+SCENES = ["plateau", "slide", "cornell", "mirror_spheres", "soft_mirrors", "window", "balls", "checkered"]  # main.cpp:44-52
+
+
+class HostScene(C.Structure):
+    _fields_ = [("n_prims", C.c_uint32), ("n_lights", C.c_uint32), ("prims", capi.Prim * capi.RTGO_MAX_PRIMS),
+                ("aabbs", capi.Aabb * capi.RTGO_MAX_PRIMS), ("lights", capi.Light * capi.RTGO_MAX_LIGHTS),
+                ("eye", C.c_float * 3), ("U", C.c_float * 3), ("V", C.c_float * 3), ("W", C.c_float * 3),
+                ("background", C.c_float * 3)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise capi.RtgoError("%s is missing: run __graft_entry__.build()" % LIB_PATH)
+        capi.load()  # librtgo_host.so links against librtgo_hip.so
+        L = C.CDLL(LIB_PATH)
+        L.rtgo_host_scene_build.restype = C.c_int
+        L.rtgo_host_scene_build.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(HostScene)]
+        L.rtgo_host_render.restype = C.c_int
+        L.rtgo_host_render.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.POINTER(capi.Stats)]
+        L.rtgo_host_last_error.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def build(name, width, height):
+    """the raw rtgo_host_scene structure"""
+    hs = HostScene()
+    rc = load().rtgo_host_scene_build(name.encode(), width, height, C.byref(hs))
+    if rc != 0:
+        raise ValueError("scene %r: %s" % (name, load().rtgo_host_last_error().decode()))
+    return hs
+
+
+def tables(name, width, height):
+    """dict(type[n], M[n,16], mat[n,10] = kd kr specularity Le, aabb[n,6], lights[nl,16], cam[12] = eye U V W, bg[3])"""
+    hs = build(name, width, height)
+    n, nl = hs.n_prims, hs.n_lights
+    prims = np.frombuffer(hs.prims, dtype=np.uint32, count=n * 27).reshape(n, 27).copy()
+    t = prims[:, 0].astype(np.int32)
+    f = prims.view(np.float32)
+    M = f[:, 1:17].copy()
+    mat = f[:, 17:27].copy()
+    aabb = np.frombuffer(hs.aabbs, dtype=np.float32, count=n * 6).reshape(n, 6).copy()
+    lights = np.frombuffer(hs.lights, dtype=np.float32, count=nl * 16).reshape(nl, 16).copy()
+    cam = np.array(list(hs.eye) + list(hs.U) + list(hs.V) + list(hs.W), dtype=np.float32)
+    return {"type": t, "M": M, "mat": mat, "aabb": aabb, "lights": lights, "cam": cam,
+            "bg": np.array(list(hs.background), dtype=np.float32)}
+
+
+def host_render(name, mode, width, height, sample=1, ambient=False, frames=1, device=0):
+    """run the headless C++ Renderer; returns (accum[h,w,4] float32, image[h,w,4] uint8, stats dict)"""
+    acc = np.empty((height, width, 4), dtype=np.float32)
+    img = np.empty((height, width, 4), dtype=np.uint8)
+    st = capi.Stats()
+    rc = load().rtgo_host_render(name.encode(), mode.encode(), width, height, sample, int(ambient), frames, device,
+                                 img.ctypes.data, acc.ctypes.data, C.byref(st))
+    if rc != 0:
+        raise capi.RtgoError("rtgo_host_render failed (%d): %s" % (rc, load().rtgo_host_last_error().decode()))
+    return acc, img, st.as_dict()

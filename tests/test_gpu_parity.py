@@ -1,0 +1,167 @@
+"""GPU parity: the HIP megakernel, called through the C ABI (include/rtgo.h), against the CPU oracle on the same
+seeded inputs.  Needs a real MI355X: run with `pytest -m gpu` on the GPU box.  Scene tables fed to the ABI here come
+from the oracle so that this file isolates the kernel; the C++ host's tables are checked in test_host_scene.py."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from parity import assert_parity, compare
+
+pytestmark = pytest.mark.gpu
+
+ALL_SCENES = ["cornell", "slide", "mirror_spheres", "plateau", "window", "checkered", "balls", "soft_mirrors"]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from raytracingo_amd import capi as m
+    m.load()
+    return m
+
+
+def upload(capi, oracle, name, W, H, with_aabbs=True):
+    sc = oracle.scene(name, W, H)
+    t = oracle.scene_tables(sc)
+    ctx = capi.Context(0)
+    ctx.set_scene(t["type"], t["M"], t["mat"], t["aabb"] if with_aabbs else None)
+    ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
+    ctx.set_background(t["bg"])
+    ctx.set_lights(t["lights"])
+    return sc, t, ctx
+
+
+def gpu_render(capi, ctx, W, H, n, frame, path, ambient=False, window=None, bands=(4, 1, 0), stats=False, prev=None):
+    x0, y0, w, h = window if window else (0, 0, W, H)
+    rows = capi.local_rows(h, bands[0], bands[1], bands[2])
+    if ctx.pixels < rows * w:
+        ctx.resize(max(rows * w, 1))
+    if prev is not None:
+        ctx.write_accum(prev)
+    ctx.launch(capi.make_frame(W, H, n, frame, path, ambient, window, bands, stats=stats))
+    ctx.sync()
+    return ctx.read_accum(rows, w), ctx.read_image(rows, w)
+
+
+def test_device_lbvh_and_inverses_bitwise(capi, oracle):
+    """what rtgo_set_scene builds on the device == the oracle's canonical LBVH and hoisted inverses, bit for bit"""
+    import ctypes as C
+    for name in ALL_SCENES:
+        for with_aabbs in (True, False):
+            sc, t, ctx = upload(capi, oracle, name, 64, 64, with_aabbs)
+            boxes, links, inv, aabb = ctx.read_bvh()
+            oboxes, olinks, _, _ = oracle.lbvh(t["aabb"])
+            assert np.array_equal(aabb.view(np.uint32), t["aabb"].view(np.uint32)), name
+            assert np.array_equal(links, olinks), name
+            assert np.array_equal(boxes.view(np.uint32), oboxes.view(np.uint32)), name
+            oinv = np.zeros((sc.n_prims, 16), dtype=np.float32)
+            for i in range(sc.n_prims):
+                m = np.ascontiguousarray(t["M"][i])
+                oracle.lib().oracle_mat_inverse(oracle.fptr(m), oracle.fptr(oinv[i]))
+            assert np.array_equal(inv.view(np.uint32), oinv[:, :12].view(np.uint32)), name
+            ctx.close()
+
+
+def test_c1_cornell_256_distributed(capi, oracle):
+    """BASELINE config 1: cornell 256x256 --mode=distributed --sample=1, frame 0"""
+    sc, t, ctx = upload(capi, oracle, "cornell", 256, 256)
+    acc, img = gpu_render(capi, ctx, 256, 256, 1, 0, path=False, stats=True)
+    racc, rimg, rc = oracle.render(sc, oracle.frame(256, 256, 1, 0, path=False, mode=1))
+    m = assert_parity(acc, racc, img, rimg, what="C1")
+    st = ctx.stats()
+    assert abs(st["rays_total"] - rc["rays_total"]) <= 0.002 * rc["rays_total"]
+    assert abs(st["rays_occlusion"] - rc["rays_occlusion"]) <= 0.002 * rc["rays_occlusion"]
+    print("C1", m, st, rc)
+
+
+@pytest.mark.parametrize("name", ["cornell", "balls", "mirror_spheres", "plateau"])
+def test_path_n4_progressive(capi, oracle, name):
+    """BASELINE scenes, path mode, N=4 (16 spp), frames 0..3 with running-average accumulation (kernel.cu:239-245)"""
+    W, H = 128, 72
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    racc = None
+    acc = None
+    for f in range(4):
+        racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, 4, f, path=True, mode=1), accum_prev=racc)
+        acc, img = gpu_render(capi, ctx, W, H, 4, f, path=True)
+        m = assert_parity(acc, racc, img, rimg, what="%s frame %d" % (name, f))
+    print(name, m)
+
+
+@pytest.mark.parametrize("name", ALL_SCENES)
+@pytest.mark.parametrize("mode", ["path", "distributed", "distributed_ambient"])
+def test_all_scenes_small(capi, oracle, name, mode):
+    W, H, n = 96, 64, 2
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    path = mode == "path"
+    amb = mode == "distributed_ambient"
+    ctx.reset_stats()
+    acc, img = gpu_render(capi, ctx, W, H, n, 0, path, amb, stats=True)
+    racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, ambient=amb, mode=1))
+    m = assert_parity(acc, racc, img, rimg, min_frac=0.985, what="%s %s" % (name, mode))
+    st = ctx.stats()
+    for k, tol in (("rays_total", 0.01), ("node_visits", 0.02), ("prim_tests", 0.02), ("hits", 0.01)):
+        assert abs(st[k] - rc[k]) <= tol * max(rc[k], 1), (k, st[k], rc[k])
+    print(name, mode, m, {k: (st[k], rc[k]) for k in ("rays_total", "node_visits", "prim_tests", "hits")})
+
+
+def test_window_and_bands_are_bitwise_the_full_frame(capi, oracle):
+    """pixels are independent (seed = tea<16>(W*y+x, frame)): any window / band split reproduces the full launch bitwise"""
+    W, H, n = 160, 90, 2
+    sc, t, ctx = upload(capi, oracle, "cornell", W, H)
+    full, fimg = gpu_render(capi, ctx, W, H, n, 0, True)
+    win = (48, 20, 70, 37)
+    part, _ = gpu_render(capi, ctx, W, H, n, 0, True, window=win)
+    assert np.array_equal(part.view(np.uint32), full[20:57, 48:118].view(np.uint32))
+    for G in (2, 3, 8):
+        out = np.zeros_like(full)
+        for g in range(G):
+            a, _ = gpu_render(capi, ctx, W, H, n, 0, True, bands=(4, G, g))
+            rows = [r for r in range(H) if (r // 4) % G == g]
+            assert a.shape[0] == len(rows)
+            out[rows] = a
+        assert np.array_equal(out.view(np.uint32), full.view(np.uint32)), G
+    # and the oracle agrees on the same split
+    ra, _, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, bands=(4, 3, 1), mode=1))
+    a, _ = gpu_render(capi, ctx, W, H, n, 0, True, bands=(4, 3, 1))
+    assert_parity(a, ra, what="band 1/3")
+
+
+def test_full_size_properties(capi, oracle):
+    """BASELINE config 2 size (1920x1080, N=4): size-independent properties + a cropped oracle comparison"""
+    W, H, n = 1920, 1080, 4
+    sc, t, ctx = upload(capi, oracle, "cornell", W, H)
+    ctx.reset_stats()
+    acc, img = gpu_render(capi, ctx, W, H, n, 0, True)
+    st = ctx.stats()
+    assert np.isfinite(acc).all() and (acc[..., 3] == 1.0).all() and (img[..., 3] == 255).all()
+    # the 8-bit image is make_color(accum) exactly (kernel.cu:90-98, 246)
+    exp = (np.clip(acc[..., :3], 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(exp, img[..., :3])
+    # every pixel traces N*N primary rays; at most 6 radiance rays per sample
+    assert 16 * W * H <= st["rays_total"] <= 6 * 16 * W * H
+    # determinism: a second launch of frame 0 is bitwise identical
+    acc2, _ = gpu_render(capi, ctx, W, H, n, 0, True)
+    assert np.array_equal(acc.view(np.uint32), acc2.view(np.uint32))
+    # crop vs oracle
+    win = (800, 400, 320, 180)
+    racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, window=win, mode=1))
+    m = assert_parity(acc[400:580, 800:1120], racc, img[400:580, 800:1120], rimg, what="1080p crop")
+    print("1080p", m, st)
+
+
+def test_error_behaviour(capi, oracle):
+    ctx = capi.Context(0)
+    with pytest.raises(capi.RtgoError):
+        ctx.launch(capi.make_frame(64, 64))  # no scene yet
+    sc, t, ctx2 = upload(capi, oracle, "cornell", 64, 64)
+    with pytest.raises(capi.RtgoError):
+        ctx2.launch(capi.make_frame(64, 64))  # no output yet
+    ctx2.resize(64 * 64)
+    with pytest.raises(capi.RtgoError):
+        ctx2.launch(capi.make_frame(64, 64, max_depth=9))
+    with pytest.raises(capi.RtgoError):
+        ctx2.launch(capi.make_frame(64, 64, window=(10, 10, 64, 64)))
+    with pytest.raises(capi.RtgoError):
+        ctx.set_scene(np.zeros(0, np.int32), np.zeros((0, 16), np.float32), np.zeros((0, 10), np.float32))
