@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the RayTracinGO hot path on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W          (default: N=1, K=20, W=5)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): cornell 1920x1080 --mode=path --sample=4 (16 spp), progressive frames.
+A step = one frame = one megakernel launch per GPU over that GPU's row bands (+ for N > 1 the RCCL gather of the 8-bit
+bands to rank 0, the only exchange on the path).  Inputs (scene, LBVH, accumulation buffer) are resident in HBM before
+the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def cpu_baseline(scene, width, height, sample, path, seconds_cap=30.0):
+    """The oracle (scalar C restatement, canonical LBVH, OpenMP over rows) timed on this host's cores: a reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+    O.build()
+    sc = O.scene(scene, width, height)
+    cores = os.cpu_count() or 1
+    # bounded sample: time a 1/16-area crop first, then the largest centred window expected to fit the cap
+    wq, hq = width // 4, height // 4
+    win = ((width - wq) // 2, (height - hq) // 2, wq, hq)
+    t0 = time.perf_counter()
+    _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, window=win, mode=1))
+    dt = time.perf_counter() - t0
+    sample_desc = "centre crop %dx%d of frame 0" % (wq, hq)
+    rate = c["rays_total"] / dt
+    # centre crops are denser than the full frame; if the full frame fits the cap, use it instead
+    full_rays_est = width * height * sample * sample * 2.3
+    if full_rays_est / rate < seconds_cap * 0.6:
+        t0 = time.perf_counter()
+        _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, mode=1))
+        dt = time.perf_counter() - t0
+        sample_desc = "full frame 0 (%dx%d, %d spp)" % (width, height, sample * sample)
+    return {"value": round(c["rays_total"] / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": sample_desc, "seconds": round(dt, 2), "rays": c["rays_total"],
+            "V": round(c["node_visits"] / c["rays_total"], 3), "T": round(c["prim_tests"] / c["rays_total"], 3),
+            "h": round(c["hits"] / c["rays_total"], 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sample", type=int, default=4)
+    ap.add_argument("--mode", default="path", choices=["path", "distributed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-frame band gather (diagnostic)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from raytracingo_amd import bands, capi, scene as hscene
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, N = args.width, args.height, args.sample
+    path = args.mode == "path"
+    band_h = 4
+    t = hscene.tables(args.scene, W, H)          # C++ host (engine::host::Scene) -> flattened tables
+    ctx = capi.Context(local_rank)
+    ctx.set_scene(t["type"], t["M"], t["mat"], t["aabb"])
+    ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
+    ctx.set_background(t["bg"])
+    ctx.set_lights(t["lights"])
+
+    rows = capi.local_rows(H, band_h, world, rank)
+    rows_pad = bands.max_local_rows(H, band_h, world)
+    accum = torch.zeros((rows_pad, W, 4), dtype=torch.float32, device=dev)
+    image = torch.zeros((rows_pad, W, 4), dtype=torch.uint8, device=dev)
+    scratch_a = torch.zeros_like(accum)
+    scratch_i = torch.zeros_like(image)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    full_image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    row_index = bands.full_row_index(H, band_h, world, rows_pad, dev) if (rank == 0 and world > 1) else None
+
+    def frame(f, stats=False):
+        return capi.make_frame(W, H, N, f, path, False, None, (band_h, world, rank), stats=stats)
+
+    def step(f):
+        ctx.launch(frame(f))
+        if world > 1 and not args.no_gather:
+            bands.gather_bands(image, H, band_h, dist, dst=0, out=full_image, row_index=row_index)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- V, T, h of the workload (instrumented kernel, untimed, into scratch buffers so the accumulation is untouched)
+    ctx.bind_output(scratch_a.data_ptr(), scratch_i.data_ptr(), rows_pad * W)
+    ctx.reset_stats()
+    ctx.launch(frame(args.warmup, stats=True))
+    ctx.sync()
+    st = ctx.stats()
+    cnt = torch.tensor([st["rays_total"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(cnt)
+    rays_s, nodes_s, tests_s, hits_s, occl_s = [float(x) for x in cnt.tolist()]
+    Vbar, Tbar, hbar = nodes_s / rays_s, tests_s / rays_s, hits_s / rays_s
+    A_ray = 32 + 32 + 32 * Vbar + 64 * Tbar + 40 * hbar
+    A_px = 36                                             # frame > 0: float4 read + float4 write + uchar4 write
+
+    # ---- warmup + timed region
+    ctx.bind_output(accum.data_ptr(), image.data_ptr(), rows_pad * W)
+    for f in range(args.warmup):
+        step(f)
+    sync_all()
+    ctx.reset_stats()
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    sync_all()
+    dt = time.perf_counter() - t0
+    st = ctx.stats()
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    rr = torch.tensor([float(st["rays_total"])], dtype=torch.float64, device=dev)
+    km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    rays_total = float(rr.item())
+    kernel_ms = float(km.item())          # slowest rank's average megakernel duration (HIP events on the launch stream)
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        mrays = rays_total / dt / 1e6
+        rays_per_launch = rays_total / args.steps
+        alg_bytes = rays_per_launch * A_ray + W * H * A_px       # whole frame (all ranks)
+        achieved = alg_bytes / world / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # per GPU, GB/s
+        out = {
+            "metric": "Mray/s + ms/frame, %s %dx%d %s spp=%d" % (args.scene, W, H, args.mode, N * N),
+            "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (procedural scene of the reference, fixed RNG seeds)",
+            "config": {"workload": "%s %dx%d --mode=%s --sample=%d (%d spp), progressive frames %d..%d" %
+                                   (args.scene, W, H, args.mode, N, N * N, args.warmup, args.warmup + args.steps - 1),
+                       "primitives": int(len(t["type"])), "tiling": "4-row bands interleaved over %d GPU(s)" % world,
+                       "gather": "RCCL gather of uchar4 bands to rank 0 per frame" if (world > 1 and not args.no_gather) else "none",
+                       "rays_per_frame": int(round(rays_per_launch))},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "rtgo::render_kernel<%s,false>" % ("true" if path else "false"),
+                         "kernel_ms": round(kernel_ms, 4), "A_ray_bytes": round(A_ray, 1), "A_px_bytes": A_px,
+                         "V": round(Vbar, 3), "T": round(Tbar, 3), "h": round(hbar, 4),
+                         "achieved_min": round((rays_per_launch * 168 + W * H * A_px) / world / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0,
+                         "mrays_roofline": round(HBM_PEAK_GBS * 1e3 / A_ray, 1),
+                         "note": "algorithmic bytes (SURVEY 8d) per launch / HIP-event kernel time; the scene is LDS-resident so physical HBM traffic is only the framebuffer"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scene, W, H, N, path)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,8 +22,11 @@ struct rtgo_ctx {
     int num_cus = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    bool ev_pending = false;
+    // ring of HIP-event pairs bracketing each megakernel launch on the launch stream (launches are asynchronous, so the
+    // elapsed times are harvested later: at rtgo_sync, or when the ring wraps)
+    static constexpr int kEvRing = 64;
+    hipEvent_t ev_start[kEvRing] = {}, ev_stop[kEvRing] = {};
+    int ev_head = 0, ev_pending = 0;
     // scene
     uint32_t n_prims = 0;
     PrimIn* d_prims_in = nullptr;
@@ -66,6 +69,21 @@ static int fail(rtgo_ctx* c, int code, const std::string& msg)
                         std::string(#call) + " failed: " + hipGetErrorString(e_) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
     } while (0)
 
+// read back the oldest `count` pending event pairs (blocks until their stop events have completed)
+static int harvest_events(rtgo_ctx* c, int count)
+{
+    while (count-- > 0 && c->ev_pending > 0) {
+        const int slot = (c->ev_head - c->ev_pending + 2 * rtgo_ctx::kEvRing) % rtgo_ctx::kEvRing;
+        RTGO_HIP(c, hipEventSynchronize(c->ev_stop[slot]));
+        float ms = 0.0f;
+        RTGO_HIP(c, hipEventElapsedTime(&ms, c->ev_start[slot], c->ev_stop[slot]));
+        c->last_ms = ms;
+        c->total_ms += ms;
+        c->ev_pending--;
+    }
+    return RTGO_OK;
+}
+
 extern "C" {
 
 uint32_t rtgo_abi_version(void) { return RTGO_ABI_VERSION; }
@@ -104,8 +122,10 @@ int rtgo_create(int device, rtgo_ctx** out)
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
     hipError_t err = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipEventCreate(&c->ev_start);
-    if (err == hipSuccess) err = hipEventCreate(&c->ev_stop);
+    for (int i = 0; i < rtgo_ctx::kEvRing && err == hipSuccess; ++i) {
+        err = hipEventCreate(&c->ev_start[i]);
+        if (err == hipSuccess) err = hipEventCreate(&c->ev_stop[i]);
+    }
     if (err == hipSuccess) err = hipMalloc(&c->d_queue, sizeof(unsigned int));
     if (err == hipSuccess) err = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long));
@@ -145,8 +165,10 @@ int rtgo_destroy(rtgo_ctx* c)
     }
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_counters);
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    for (int i = 0; i < rtgo_ctx::kEvRing; ++i) {
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return RTGO_OK;
@@ -325,15 +347,21 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
 
     RTGO_HIP(c, hipSetDevice(c->device));
     RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
-    RTGO_HIP(c, hipEventRecord(c->ev_start, c->stream));
+    if (c->ev_pending == rtgo_ctx::kEvRing) {
+        int rc = harvest_events(c, 1);
+        if (rc) return rc;
+    }
+    const int slot = c->ev_head;
+    RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
     if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
     else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
     else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
     else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
     RTGO_HIP(c, hipGetLastError());
-    RTGO_HIP(c, hipEventRecord(c->ev_stop, c->stream));
-    c->ev_pending = true;
+    RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
+    c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;
+    c->ev_pending++;
     c->launches++;
     return RTGO_OK;
 }
@@ -343,14 +371,7 @@ int rtgo_sync(rtgo_ctx* c)
     if (!c) return RTGO_E_INVALID;
     RTGO_HIP(c, hipSetDevice(c->device));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->ev_pending) {
-        float ms = 0.0f;
-        RTGO_HIP(c, hipEventElapsedTime(&ms, c->ev_start, c->ev_stop));
-        c->last_ms = ms;
-        c->total_ms += ms;
-        c->ev_pending = false;
-    }
-    return RTGO_OK;
+    return harvest_events(c, c->ev_pending);
 }
 
 static int copy_out(rtgo_ctx* c, void* host, const void* dev, size_t bytes, size_t elem)

@@ -1,0 +1,178 @@
+"""The oracle as a whole: regression against its committed renders, literal mode == LBVH mode, window/band identity,
+the intersection programs' edge cases, GetRayOnHemisphere, canonical LBVH invariants."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_committed_renders_reproduce_bitwise(oracle):
+    z = np.load(os.path.join(GOLD, "oracle_renders.npz"))
+    with open(os.path.join(GOLD, "oracle_renders.json")) as f:
+        meta = json.load(f)["cases"]
+    for i, m in enumerate(meta):
+        sc = oracle.scene(m["name"], m["W"], m["H"])
+        acc = None
+        for fr in range(m["frames"]):
+            acc, img, c = oracle.render(sc, oracle.frame(m["W"], m["H"], m["N"], fr, path=m["path"], ambient=m["ambient"], mode=1), accum_prev=acc)
+        assert np.array_equal(acc.view(np.uint32), z["accum_%d" % i].view(np.uint32)), m
+        assert np.array_equal(img, z["image_%d" % i]), m
+        assert c == m["counters_last_frame"], m
+
+
+@pytest.mark.parametrize("name", ["cornell", "slide", "mirror_spheres", "plateau", "window", "checkered", "balls", "soft_mirrors"])
+def test_literal_mode_equals_lbvh_mode(oracle, name):
+    """mode 0 = the reference's statement (brute force in SBT order, inverse() per intersection call);
+    mode 1 = canonical LBVH + hoisted inverse. Same image bit for bit, same ray counts."""
+    W, H = (40, 24) if name == "checkered" else (64, 40)
+    sc = oracle.scene(name, W, H)
+    for path, amb in ((True, False), (False, False), (False, True)):
+        a0, i0, c0 = oracle.render(sc, oracle.frame(W, H, 2, 0, path=path, ambient=amb, mode=0))
+        a1, i1, c1 = oracle.render(sc, oracle.frame(W, H, 2, 0, path=path, ambient=amb, mode=1))
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)), (name, path, amb)
+        assert np.array_equal(i0, i1)
+        assert c0["rays_total"] == c1["rays_total"] and c0["hits"] == c1["hits"]
+        assert c1["prim_tests"] <= c0["prim_tests"]
+
+
+def test_windows_and_bands_are_the_full_image(oracle):
+    W, H, N = 96, 54, 2
+    sc = oracle.scene("mirror_spheres", W, H)
+    full, fimg, _ = oracle.render(sc, oracle.frame(W, H, N, 3, path=True, mode=1), accum_prev=np.full((H, W, 4), 0.25, np.float32))
+    win = (17, 9, 40, 30)
+    part, _, _ = oracle.render(sc, oracle.frame(W, H, N, 3, path=True, window=win, mode=1), accum_prev=np.full((30, 40, 4), 0.25, np.float32))
+    assert np.array_equal(part.view(np.uint32), full[9:39, 17:57].view(np.uint32))
+    for G in (2, 3, 5):
+        out = np.zeros_like(full)
+        for g in range(G):
+            rows = [r for r in range(H) if (r // 4) % G == g]
+            a, _, _ = oracle.render(sc, oracle.frame(W, H, N, 3, path=True, bands=(4, G, g), mode=1), accum_prev=np.full((len(rows), W, 4), 0.25, np.float32))
+            out[rows] = a
+        assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
+
+
+def test_progressive_accumulation_is_a_running_mean(oracle):
+    W, H = 48, 27
+    sc = oracle.scene("cornell", W, H)
+    acc, frames = None, []
+    for f in range(4):
+        single, _, _ = oracle.render(sc, oracle.frame(W, H, 2, f, path=True, mode=1))  # frame f alone would need frame_count=0 ...
+        acc, img, _ = oracle.render(sc, oracle.frame(W, H, 2, f, path=True, mode=1), accum_prev=acc)
+    # lerp(prev, cur, 1/(f+1)) keeps the accumulation a convex combination: bounded by the per-frame extremes, alpha = 1
+    assert (acc[..., 3] == 1.0).all() and np.isfinite(acc).all()
+    assert np.array_equal(img[..., :3], (np.clip(acc[..., :3], 0, 1) * np.float32(255.0)).astype(np.uint8))
+
+
+def _prim(oracle, ptype, M=None):
+    p = oracle.Prim()
+    p.type = ptype
+    m = np.eye(4, dtype=np.float32).reshape(-1) if M is None else np.asarray(M, dtype=np.float32).reshape(-1)
+    p.M[:] = m.tolist()
+    return p
+
+
+def _isect(oracle, prim, o, d):
+    t = C.c_float(0)
+    n = np.zeros(3, dtype=np.float32)
+    o, d = oracle.f32(o), oracle.f32(d)
+    hit = oracle.lib().oracle_intersect(C.byref(prim), oracle.fptr(o), oracle.fptr(d), C.byref(t), oracle.fptr(n))
+    return bool(hit), t.value, n
+
+
+def test_sphere_near_root_only(oracle):
+    s = _prim(oracle, oracle.SPHERE)
+    hit, t, n = _isect(oracle, s, [0, 0, 5], [0, 0, -1])
+    assert hit and abs(t - 4.0) < 1e-6 and np.allclose(n, [0, 0, 1])
+    assert not _isect(oracle, s, [0, 0, 0], [0, 0, -1])[0]      # origin inside: far root is never reported (kernel.cu:268)
+    assert not _isect(oracle, s, [0, 2, 5], [0, 0, -1])[0]      # misses
+    assert not _isect(oracle, s, [0, 0, -5], [0, 0, -1])[0]     # behind
+
+
+def test_rectangle_is_one_sided_and_open(oracle):
+    r = _prim(oracle, oracle.RECTANGLE)
+    hit, t, n = _isect(oracle, r, [0.1, 2, -0.2], [0, -1, 0])
+    assert hit and abs(t - 2.0) < 1e-6 and np.allclose(n, [0, 1, 0])
+    assert not _isect(oracle, r, [0.1, -2, -0.2], [0, 1, 0])[0]     # from below: back face culled (kernel.cu:400)
+    assert not _isect(oracle, r, [0.5, 2, 0.0], [0, -1, 0])[0]      # exactly on the edge: strict inequalities
+    assert not _isect(oracle, r, [0.6, 2, 0.0], [0, -1, 0])[0]
+    assert not _isect(oracle, r, [0, 2, 0], [1, 0, 0])[0]           # parallel: divisor == 0
+
+
+def test_disk_two_sided_with_grazing_cutoff(oracle):
+    d = _prim(oracle, oracle.DISK)
+    assert _isect(oracle, d, [0.3, 1, 0.3], [0, -1, 0])[0]
+    assert _isect(oracle, d, [0.3, -1, 0.3], [0, 1, 0])[0]          # two-sided
+    assert not _isect(oracle, d, [0.8, 1, 0.8], [0, -1, 0])[0]      # outside radius
+    assert not _isect(oracle, d, [-50, 0.4, 0], [1, -0.009, 0])[0]  # |d.y| < 0.01 rejected (kernel.cu:347)
+    assert _isect(oracle, d, [-20, 0.4, 0], [1, -0.02, 0])[0]
+
+
+def test_cylinder_open_both_roots(oracle):
+    c = _prim(oracle, oracle.CYLINDER)
+    hit, t, n = _isect(oracle, c, [0, 0, 5], [0, 0, -1])
+    assert hit and abs(t - 4.0) < 1e-6 and np.allclose(n, [0, 0, 1])
+    hit, t, n = _isect(oracle, c, [0, 0, 0], [0, 0, -1])            # from inside: far root is valid for cylinders
+    assert hit and abs(t - 1.0) < 1e-6
+    # looking down the open end: near root is above the cap (|y| >= 1), far root inside the tube wall
+    hit, t, n = _isect(oracle, c, [0, 1.5, -2], [0, -0.3, 1])
+    assert hit and abs(t - 3.0) < 1e-5 and np.allclose(n, [0, 0, 1], atol=1e-6)
+    assert not _isect(oracle, c, [0, 3, 0], [0, -1, 0])[0]          # along the axis: a = 0 -> discr = 0 <= eps
+
+
+def test_transformed_normal_uses_inverse_transpose(oracle):
+    M = np.eye(4, dtype=np.float32)
+    M[0, 0], M[1, 1], M[2, 2] = 2, 1, 1   # sphere stretched along x
+    s = _prim(oracle, oracle.SPHERE, M)
+    hit, t, n = _isect(oracle, s, [5, 0, 0], [-1, 0, 0])
+    assert hit and abs(t - 3.0) < 1e-6 and np.allclose(n / np.linalg.norm(n), [1, 0, 0])
+    hit, t, n = _isect(oracle, s, [1.0, 5, 0], [0, -1, 0])
+    assert hit and n[0] > 0 and n[1] > 0 and abs(n[0] / n[1] - (0.5 * 0.5) / np.sqrt(1 - 0.25)) < 1e-5
+
+
+def test_hemisphere_sampling(oracle):
+    L = oracle.lib()
+    nrm = oracle.f32([0.3, 0.9, -0.2])
+    nrm = nrm / np.linalg.norm(nrm)
+    seed = C.c_uint32(1234)
+    out = np.zeros(3, dtype=np.float32)
+    cos_sum = 0.0
+    for _ in range(2000):
+        L.oracle_hemisphere(oracle.fptr(nrm), oracle.fptr(nrm), 0.0, C.byref(seed), oracle.fptr(out))
+        assert abs(np.linalg.norm(out) - 1) < 1e-5 and float(out @ nrm) >= 0
+        cos_sum += float(out @ nrm)
+    assert abs(cos_sum / 2000 - 0.5) < 0.03       # coefficient 0: cos(theta) = 1 - r2 is uniform on [0,1]
+    d = oracle.f32([0.6, 0.64, 0.48])
+    for coef in (100.0, 1e5):
+        for _ in range(200):
+            L.oracle_hemisphere(oracle.fptr(nrm), oracle.fptr(d), coef, C.byref(seed), oracle.fptr(out))
+            assert float(out @ (d / np.linalg.norm(d))) > (0.9 if coef == 100.0 else 0.9995)
+            assert float(out @ nrm) >= 0
+
+
+@pytest.mark.parametrize("name", ["cornell", "balls", "checkered", "slide"])
+def test_lbvh_invariants(oracle, name):
+    t = oracle.scene_tables(oracle.scene(name, 64, 64))
+    n = len(t["type"])
+    boxes, links, code, order = oracle.lbvh(t["aabb"])
+    assert sorted(order.tolist()) == list(range(n))
+    keys = [(int(c), int(o)) for c, o in zip(code, order)]
+    assert keys == sorted(keys)
+    seen, depth = set(), 0
+    stack = [(0, 0)]
+    while stack:
+        k, d = stack.pop()
+        depth = max(depth, d)
+        if links[k, 1] < 0:
+            assert k >= n - 1 and np.array_equal(boxes[k], t["aabb"][links[k, 0]])
+            seen.add(int(links[k, 0]))
+        else:
+            for ch in links[k]:
+                assert (boxes[k, :3] <= boxes[ch, :3]).all() and (boxes[k, 3:] >= boxes[ch, 3:]).all()
+                stack.append((int(ch), d + 1))
+            assert np.array_equal(boxes[k, :3], np.minimum(boxes[links[k, 0], :3], boxes[links[k, 1], :3]))
+            assert np.array_equal(boxes[k, 3:], np.maximum(boxes[links[k, 0], 3:], boxes[links[k, 1], 3:]))
+    assert seen == set(range(n)) and depth <= 24
