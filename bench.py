@@ -96,7 +96,11 @@ def main():
     image = torch.zeros((rows_pad, W, 4), dtype=torch.uint8, device=dev)
     scratch_a = torch.zeros_like(accum)
     scratch_i = torch.zeros_like(image)
-    stream = torch.cuda.current_stream(dev)
+    # one explicit (non-default) HIP stream carries the megakernel AND everything torch enqueues (the RCCL gather waits
+    # on it), so kernel -> gather ordering is by stream; the ABI treats a NULL stream as "use the context's own"
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     full_image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
     row_index = bands.full_row_index(H, band_h, world, rows_pad, dev) if (rank == 0 and world > 1) else None

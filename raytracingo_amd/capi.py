@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "librtgo_hip.so")
+# RTGO_HIP_LIB: developer override to A/B an experimental build of the same ABI (never a different backend)
+LIB_PATH = os.environ.get("RTGO_HIP_LIB") or os.path.join(PKG_DIR, "librtgo_hip.so")
 
 RTGO_MAX_PRIMS = 512
 RTGO_MAX_LIGHTS = 10

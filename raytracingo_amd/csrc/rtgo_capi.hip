@@ -5,6 +5,7 @@
 #include "rtgo_device.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,8 +34,12 @@ struct rtgo_ctx {
     float* d_aabb = nullptr;
     float4* d_nodes = nullptr;
     float4* d_prims = nullptr;
+    float4* d_fnodes = nullptr;   // collapsed LBVH of the fast walk
+    float4* d_fprims = nullptr;   // Morton-ordered traversal records of the fast walk
     int* d_meta = nullptr;
     int lbvh_depth = 0;
+    int fast_depth = 0;
+    int leaf_budget = kDefaultLeafBudget;
     LightRec* d_lights = nullptr;
     int n_lights = 0;
     bool have_camera = false;
@@ -138,6 +143,7 @@ int rtgo_create(int device, rtgo_ctx** out)
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    if (err == hipSuccess) err = hipDeviceSynchronize();  // the null-stream memsets above must land before any launch
     if (err != hipSuccess) {
         std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
         rtgo_destroy(c);
@@ -157,6 +163,8 @@ int rtgo_destroy(rtgo_ctx* c)
     (void)hipFree(c->d_aabb);
     (void)hipFree(c->d_nodes);
     (void)hipFree(c->d_prims);
+    (void)hipFree(c->d_fnodes);
+    (void)hipFree(c->d_fprims);
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_lights);
     if (c->own_output) {
@@ -194,6 +202,10 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     (void)hipFree(c->d_aabb);
     (void)hipFree(c->d_nodes);
     (void)hipFree(c->d_prims);
+    (void)hipFree(c->d_fnodes);
+    (void)hipFree(c->d_fprims);
+    c->d_fnodes = nullptr;
+    c->d_fprims = nullptr;
     c->d_prims_in = nullptr;
     c->d_aabb = nullptr;
     c->d_nodes = nullptr;
@@ -203,15 +215,23 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     RTGO_HIP(c, hipMalloc(&c->d_aabb, n * 6 * sizeof(float)));
     RTGO_HIP(c, hipMalloc(&c->d_nodes, (2 * n - 1) * 2 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->d_prims, n * 6 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->d_fnodes, (2 * n - 1) * 2 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->d_fprims, n * 4 * sizeof(float4)));
+    if (const char* k = std::getenv("RTGO_LEAF_BUDGET")) {  // tuning knob for experiments; results do not depend on it
+        const int v = std::atoi(k);
+        if (v >= 0 && v <= 16 * kMaxPrims) c->leaf_budget = v;
+    }
     RTGO_HIP(c, hipMemcpyAsync(c->d_prims_in, prims, n * sizeof(PrimIn), hipMemcpyHostToDevice, c->stream));
     if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), 0, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
-                       c->d_nodes, c->d_prims, c->d_meta);
+                       c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget, c->d_meta);
     RTGO_HIP(c, hipGetLastError());
-    int depth = 0;
-    RTGO_HIP(c, hipMemcpyAsync(&depth, c->d_meta, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    int meta[2] = {0, 0};
+    RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    const int depth = meta[0];
     c->lbvh_depth = depth;
+    c->fast_depth = meta[1];
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
                                                std::to_string(kStackDepth) + ")");
@@ -317,6 +337,10 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.n_tiles = p.tiles_x * ((p.local_rows + kTileH - 1) / kTileH);
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
+    p.fnodes = c->d_fnodes;
+    p.fprims = c->d_fprims;
+    const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
+    p.stack_depth = stats ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
     p.lights = c->d_lights;
     p.accum = c->d_accum;
     p.image = c->d_image;
@@ -336,11 +360,12 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.bg = c->bg;
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
-    const size_t lds = (size_t)(2 * p.n_nodes + 6 * p.n_prims) * sizeof(float4) + (size_t)kStackDepth * kBlock * sizeof(float2) +
-                       (size_t)kMaxLights * sizeof(LightRec);
+    // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim
+    const size_t lds = (size_t)(2 * p.n_nodes + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
+                       (size_t)p.stack_depth * kBlock * sizeof(float2) + (size_t)kMaxLights * sizeof(LightRec);
     int blocks_per_cu = (int)((160 * 1024) / lds);
     if (blocks_per_cu < 1) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
-    if (blocks_per_cu > 4) blocks_per_cu = 4;
+    if (blocks_per_cu > 4) blocks_per_cu = 4;  // 16 waves per CU = 4 per SIMD is what the kernel's VGPR budget admits
     unsigned int grid = (unsigned int)(c->num_cus * blocks_per_cu);
     const unsigned int need = (p.n_tiles + (kBlock / 64) - 1) / (kBlock / 64);
     if (grid > need) grid = need;
@@ -353,7 +378,6 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
     if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
     else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
     else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
@@ -381,7 +405,8 @@ static int copy_out(rtgo_ctx* c, void* host, const void* dev, size_t bytes, size
     if (bytes > c->pixels * elem) return fail(c, RTGO_E_INVALID, "rtgo_read: more bytes than the output holds");
     int rc = rtgo_sync(c);
     if (rc) return rc;
-    RTGO_HIP(c, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+    RTGO_HIP(c, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
     return RTGO_OK;
 }
 
@@ -395,7 +420,8 @@ int rtgo_write_accum(rtgo_ctx* c, const void* host, size_t bytes)
     if (bytes > c->pixels * sizeof(float4)) return fail(c, RTGO_E_INVALID, "rtgo_write_accum: too many bytes");
     int rc = rtgo_sync(c);
     if (rc) return rc;
-    RTGO_HIP(c, hipMemcpy(c->d_accum, host, bytes, hipMemcpyHostToDevice));
+    RTGO_HIP(c, hipMemcpyAsync(c->d_accum, host, bytes, hipMemcpyHostToDevice, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
     return RTGO_OK;
 }
 
@@ -405,7 +431,8 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     int rc = rtgo_sync(c);
     if (rc) return rc;
     unsigned long long h[8];
-    RTGO_HIP(c, hipMemcpy(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost));
+    RTGO_HIP(c, hipMemcpyAsync(h, c->d_counters, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
     out->rays_total = h[0];
     out->rays_occlusion = h[1];
     out->node_visits = h[2];
@@ -423,7 +450,9 @@ int rtgo_reset_stats(rtgo_ctx* c)
     if (!c) return RTGO_E_INVALID;
     int rc = rtgo_sync(c);
     if (rc) return rc;
-    RTGO_HIP(c, hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long)));
+    // on the launch stream: a memset on the null stream is not ordered against a non-blocking stream's kernels
+    RTGO_HIP(c, hipMemsetAsync(c->d_counters, 0, 8 * sizeof(unsigned long long), c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
     c->total_ms = 0.0f;
     c->last_ms = 0.0f;
     c->launches = 0;

@@ -14,7 +14,8 @@
 namespace rtgo {
 
 constexpr int kBlock = 256;          // 4 waves per workgroup
-constexpr int kStackDepth = 24;      // per-lane traversal stack entries (LBVH depth is checked against it at build)
+constexpr int kStackDepth = 24;      // per-lane traversal stack entries of the canonical walk (LBVH depth is checked against it at build)
+constexpr int kDefaultLeafBudget = 32;  // fast walk: LBVH subtrees whose leaf-test cost is <= this many rectangle tests become one leaf
 constexpr int kTileW = 16, kTileH = 4;  // one wave = 16x4 pixels: 256-byte float4 rows, 4-row bands for multi-GPU
 constexpr int kMaxPrims = 512;
 constexpr int kMaxLights = 10;
@@ -36,8 +37,11 @@ struct LightRec {
 };
 
 struct LaunchParams {
-    const float4* nodes;
-    const float4* prims;
+    const float4* nodes;            // canonical LBVH, 2 float4 per node
+    const float4* prims;            // 6 float4 per primitive, SBT order
+    const float4* fnodes;           // collapsed LBVH for the fast walk: same indexing, subtrees of <= K primitives are leaves
+    const float4* fprims;           // 4 float4 per primitive in Morton order: rows 0..2 of M^-1, (bits(type), bits(SBT index), 0, 0)
+    int stack_depth;                // per-lane LDS stack entries this launch needs
     const LightRec* lights;
     float4* accum;
     uchar4* image;
@@ -312,6 +316,213 @@ __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, 
     return best.prim >= 0;
 }
 
+// =====================================================================================================================
+// Fast walk (the kernel that is timed).  Same closest hit, bit for bit, as the canonical walk above -- every accepted
+// candidate goes through the same intersection arithmetic and the same acceptance rule -- but organised for the SIMDs:
+//   * LBVH subtrees of <= K primitives are collapsed into one leaf whose primitives sit contiguously (Morton order), so
+//     a wave spends its time in short uniform primitive loops instead of divergent one-primitive leaves;
+//   * while-while structure: all lanes first descend to their next leaf, then all lanes with a leaf test it;
+//   * the slab test is 6 FMAs on a reciprocal direction (v_rcp_f32): it only steers culling, which stays conservative
+//     because every reference AABB is padded by 1e-3 (primitive.cpp:16,62-67), three orders above the rounding at stake;
+//   * rejections that need no division come first (rectangle: d.y >= 0 or o.y <= 0 in object space can never pass
+//     kernel.cu:394-400), and the normal is transformed once, for the winner only.
+// =====================================================================================================================
+struct FastHit {
+    float t;
+    v3 nobj;   // object-space normal of the winner (kernel.cu:270,315,345,388 before TransformNormal)
+    int pos;   // Morton position of the winner
+    int orig;  // its SBT index (tie-break + material lookup)
+};
+
+__device__ __forceinline__ bool closer(float t, int orig, float tmin, const FastHit& best)
+{
+    return t > tmin && (t < best.t || (t == best.t && best.orig >= 0 && orig < best.orig));
+}
+
+__device__ __forceinline__ void leaf_test(const float4* __restrict__ s_fprims, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+    const float4 r1 = s_fprims[4 * pos + 1];
+    const float4 meta = s_fprims[4 * pos + 3];
+    const int type = __float_as_int(meta.x), orig = __float_as_int(meta.y);
+    if (type == 2) {  // rectangle
+        const float dy = r1.x * wd.x + r1.y * wd.y + r1.z * wd.z;
+        if (dy < 0.0f) {
+            const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
+            if (oy > 0.0f) {
+                const float t = (0.0f - oy) / dy;
+                if (t > 0.0001f && closer(t, orig, tmin, best)) {
+                    const float4 r0 = s_fprims[4 * pos + 0], r2 = s_fprims[4 * pos + 2];
+                    const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
+                    const float ox = r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, oz = r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w;
+                    const float px = ox + t * dx, pz = oz + t * dz;
+                    const float u = px + 0.5f, v = -(pz - 0.5f);
+                    if (0.0f < u && u < 1.0f && 0.0f < v && v < 1.0f) {
+                        best.t = t;
+                        best.nobj = mk(0.0f, 1.0f, 0.0f);
+                        best.pos = pos;
+                        best.orig = orig;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    const float4 r0 = s_fprims[4 * pos + 0], r2 = s_fprims[4 * pos + 2];
+    const v3 d = xf_dir(r0, r1, r2, wd);
+    const v3 o = xf_point(r0, r1, r2, wo);
+    if (type == 3) {  // sphere
+        const float a = vdot(d, d);
+        const float b = 2.0f * vdot(d, o);
+        const float c = vdot(o, o) - 1.0f;
+        const float discr = b * b - 4.0f * a * c;
+        if (discr > 0.0f) {
+            const float sdiscr = sqrtf(discr);
+            const float t = (-b - sdiscr) / (2.0f * a);
+            if (t > 0.0001f && closer(t, orig, tmin, best)) {
+                best.t = t;
+                best.nobj = vnormalize(vadd(o, vscale(d, t)));
+                best.pos = pos;
+                best.orig = orig;
+            }
+        }
+    } else if (type == 0) {  // cylinder
+        const float a = d.x * d.x + d.z * d.z;
+        const float b = 2.0f * (o.x * d.x + o.z * d.z);
+        const float c = o.x * o.x + o.z * o.z - 1.0f;
+        const float discr = b * b - 4.0f * a * c;
+        if (discr > 0.001f) {
+            const float sdiscr = sqrtf(discr);
+            const float t0 = (-b + sdiscr) / (2.0f * a);
+            const float t1 = (-b - sdiscr) / (2.0f * a);
+            float t = 1e16f;
+            bool valid = false;
+            if (t0 > 0.001f) {
+                const float py = o.y + t0 * d.y;
+                if (py > -1.0f && py < 1.0f) {
+                    t = t0;
+                    valid = true;
+                }
+            }
+            if (t1 > 0.001f && t1 < t) {
+                const float py = o.y + t1 * d.y;
+                if (py > -1.0f && py < 1.0f) {
+                    t = t1;
+                    valid = true;
+                }
+            }
+            if (valid && closer(t, orig, tmin, best)) {
+                best.t = t;
+                best.nobj = mk(o.x + t * d.x, 0.0f, o.z + t * d.z);
+                best.pos = pos;
+                best.orig = orig;
+            }
+        }
+    } else {  // disk
+        const float divisor = d.y;
+        if (!(divisor > 0.0f - 0.01f && divisor < 0.0f + 0.01f)) {
+            const float t = (-o.y) / divisor;
+            if (t > 0.0001f && closer(t, orig, tmin, best)) {
+                const v3 p = vadd(o, vscale(d, t));
+                if (vdot(p, p) < 1.0f) {
+                    best.t = t;
+                    best.nobj = mk(0.0f, 1.0f, 0.0f);
+                    best.pos = pos;
+                    best.orig = orig;
+                }
+            }
+        }
+    }
+}
+
+// conservative slab test: t = fma(b, 1/d, -o/d) with the hardware reciprocal
+__device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id, v3 noid, float tmin, float tmax, float& tn_out)
+{
+    float t0 = fmaf(q0.x, id.x, noid.x), t1 = fmaf(q1.x, id.x, noid.x);
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = fmaf(q0.y, id.y, noid.y);
+    t1 = fmaf(q1.y, id.y, noid.y);
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    t0 = fmaf(q0.z, id.z, noid.z);
+    t1 = fmaf(q1.z, id.z, noid.z);
+    tn = fmaxf(tn, fminf(t0, t1));
+    tf = fminf(tf, fmaxf(t0, t1));
+    tn = fmaxf(tn, tmin);
+    tf = fminf(tf, tmax);
+    tn_out = tn;
+    // widen by a few ulps so that the reciprocal's rounding can never drop a box the exact test keeps
+    return tn <= tf * 1.000002f + 1e-7f;
+}
+
+__device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
+                                                 float2* __restrict__ s_stack, v3 o, v3 d, float tmin, float tmax, Hit& out)
+{
+    FastHit best;
+    best.t = tmax;
+    best.nobj = mk(0.0f, 0.0f, 0.0f);
+    best.pos = -1;
+    best.orig = -1;
+    const v3 id = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
+    float tn;
+    const float4 q0 = s_fnodes[0], q1 = s_fnodes[1];
+    out.prim = -1;
+    out.t = tmax;
+    out.n = mk(0.0f, 0.0f, 0.0f);
+    if (!box_fast(q0, q1, id, noid, tmin, best.t, tn)) return false;
+    int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
+    int sp = 0;
+    bool have = true;
+    auto pop = [&]() -> bool {
+        while (sp > 0) {
+            --sp;
+            const float2 e = s_stack[sp * kBlock];
+            if (e.x <= best.t) {
+                const int idx = __float_as_int(e.y);
+                left = __float_as_int(s_fnodes[2 * idx].w);
+                right = __float_as_int(s_fnodes[2 * idx + 1].w);
+                return true;
+            }
+        }
+        return false;
+    };
+    while (have) {
+        while (have && right >= 0) {
+            const float4 l0 = s_fnodes[2 * left], l1 = s_fnodes[2 * left + 1];
+            const float4 h0 = s_fnodes[2 * right], h1 = s_fnodes[2 * right + 1];
+            float tl, tr;
+            const bool hl = box_fast(l0, l1, id, noid, tmin, best.t, tl);
+            const bool hr = box_fast(h0, h1, id, noid, tmin, best.t, tr);
+            if (hl && hr) {
+                const bool swap = tr < tl;
+                s_stack[sp * kBlock] = make_float2(swap ? tl : tr, __int_as_float(swap ? left : right));
+                ++sp;
+                left = __float_as_int(swap ? h0.w : l0.w);
+                right = __float_as_int(swap ? h1.w : l1.w);
+            } else if (hl) {
+                left = __float_as_int(l0.w);
+                right = __float_as_int(l1.w);
+            } else if (hr) {
+                left = __float_as_int(h0.w);
+                right = __float_as_int(h1.w);
+            } else {
+                have = pop();
+            }
+        }
+        if (have) {
+            const int first = left, cnt = -right;
+            for (int k = 0; k < cnt; ++k) leaf_test(s_fprims, first + k, o, d, tmin, best);
+            have = pop();
+        }
+    }
+    if (best.pos < 0) return false;
+    const float4 r0 = s_fprims[4 * best.pos + 0], r1 = s_fprims[4 * best.pos + 1], r2 = s_fprims[4 * best.pos + 2];
+    out.t = best.t;
+    out.n = xf_normal(r0, r1, r2, best.nobj);
+    out.prim = best.orig;
+    return true;
+}
+
 // GetRayOnHemisphere, kernel.cu:101-122
 __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed)
 {
@@ -366,14 +577,27 @@ template <bool PATH, bool STATS>
 __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
+    //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][stack][lights]
+    constexpr int MS = STATS ? 6 : 3;  // float4 stride between two primitives' material rows (kd|spec, kr|type, Le)
     float4* s_nodes = reinterpret_cast<float4*>(smem);
     float4* s_prims = s_nodes + 2 * p.n_nodes;
-    float2* s_stack_base = reinterpret_cast<float2*>(s_prims + 6 * p.n_prims);
-    LightRec* s_lights = reinterpret_cast<LightRec*>(s_stack_base + kStackDepth * kBlock);
+    float4* s_mat_w = STATS ? s_prims + 3 : s_prims + 4 * p.n_prims;
+    float4* s_end = STATS ? s_prims + 6 * p.n_prims : s_mat_w + 3 * p.n_prims;
+    float2* s_stack_base = reinterpret_cast<float2*>(s_end);
+    const int stack_depth = STATS ? kStackDepth : p.stack_depth;
+    LightRec* s_lights = reinterpret_cast<LightRec*>(s_stack_base + stack_depth * kBlock);
+    const float4* s_mat = s_mat_w;
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.nodes[i];
-    for (int i = tid; i < 6 * p.n_prims; i += kBlock) s_prims[i] = p.prims[i];
+    if (STATS) {
+        for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.nodes[i];
+        for (int i = tid; i < 6 * p.n_prims; i += kBlock) s_prims[i] = p.prims[i];
+    } else {
+        for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.fnodes[i];
+        for (int i = tid; i < 4 * p.n_prims; i += kBlock) s_prims[i] = p.fprims[i];
+        for (int i = tid; i < 3 * p.n_prims; i += kBlock) s_mat_w[i] = p.prims[6 * (i / 3) + 3 + (i % 3)];
+    }
     {
         const float* src = reinterpret_cast<const float*>(p.lights);
         float* dst = reinterpret_cast<float*>(s_lights);
@@ -451,7 +675,9 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
             if (alive) {
                 Hit h;
                 c_rays += 1;
-                const bool hit = closest_hit<STATS>(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h, c_nodes, c_tests);
+                bool hit;
+                if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h, c_nodes, c_tests);
+                else hit = closest_hit_fast(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h);
                 if (STATS && hit) c_hits += 1;
 
                 bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
@@ -463,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
                         done = true;
                     } else {
                         // __closesthit__ch, path branch: kernel.cu:426-475
-                        const float4 m3 = s_prims[6 * h.prim + 3], m5 = s_prims[6 * h.prim + 5];
+                        const float4 m3 = s_mat[MS * h.prim + 0], m5 = s_mat[MS * h.prim + 2];
                         v3 N = vnormalize(h.n);
                         const float t = h.t;
                         const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
@@ -495,11 +721,11 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
                         c_occl += 1;
                         v3 illum = mk(1.0f, 1.0f, 1.0f);  // occlusion miss leaves the payload untouched
                         if (hit) {
-                            const float4 b5 = s_prims[6 * h.prim + 5];
+                            const float4 b5 = s_mat[MS * h.prim + 2];
                             illum = mk(fminf(b5.x, 1.0f), fminf(b5.y, 1.0f), fminf(b5.z, 1.0f));
                         }
                         const LightRec& L = s_lights[sLight];
-                        const float4 m3 = s_prims[6 * sPrim + 3];
+                        const float4 m3 = s_mat[MS * sPrim + 0];
                         const v3 kd = mk(m3.x, m3.y, m3.z);
                         const float spec = m3.w;
                         const v3 Lm = rd;
@@ -543,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
                         done = true;
                     } else {
                         // __closesthit__ch, distributed branch up to the shadow trace: kernel.cu:426-455, 477-499
-                        const float4 m5 = s_prims[6 * h.prim + 5];
+                        const float4 m5 = s_mat[MS * h.prim + 2];
                         v3 N = vnormalize(h.n);
                         const float t = h.t;
                         const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
@@ -589,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
                             if (PATH) {
                                 term = vmul(lvA[k], term);
                             } else {
-                                const float4 m3 = s_prims[6 * lvPrim[k] + 3], m4 = s_prims[6 * lvPrim[k] + 4];
+                                const float4 m3 = s_mat[MS * lvPrim[k] + 0], m4 = s_mat[MS * lvPrim[k] + 1];
                                 term = vadd(lvA[k], vmul(mk(m4.x, m4.y, m4.z), term));
                                 if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
                             }
@@ -732,7 +958,8 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
 // out_meta[0] = tree depth (levels below the root that a traversal stack may need)
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
-                                                          float4* __restrict__ out_prims, int* __restrict__ out_meta)
+                                                          float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
+                                                          float4* __restrict__ out_fprims, int leaf_budget, int* __restrict__ out_meta)
 {
     __shared__ float s_box[kMaxPrims][6];
     __shared__ unsigned long long s_keys[kMaxPrims];
@@ -740,11 +967,17 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     __shared__ int s_left[kMaxPrims], s_right[kMaxPrims];
     __shared__ int s_parent[2 * kMaxPrims];
     __shared__ int s_visit[kMaxPrims];
-    __shared__ float s_red[6][kMaxPrims];
-    __shared__ int s_depth;
+    __shared__ int s_wt[2 * kMaxPrims];  // fast walk: cost weight of each subtree
+    __shared__ short s_lo[kMaxPrims], s_hi[kMaxPrims];  // Morton range covered by each internal node
+    __shared__ int s_depth, s_fdepth;
+    // the bounds reduction runs before s_nbox is first written: reuse its storage (keeps static LDS under 64 KiB)
+    float(*s_red)[kMaxPrims] = reinterpret_cast<float(*)[kMaxPrims]>(&s_nbox[0][0]);
 
     const int i = threadIdx.x;
-    if (i == 0) s_depth = 0;
+    if (i == 0) {
+        s_depth = 0;
+        s_fdepth = 0;
+    }
     // ---- per primitive: inverse, record, AABB
     if (i < n) {
         const PrimIn P = prims[i];
@@ -842,30 +1075,34 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         const int right = (hi == gamma + 1) ? leaf0 + gamma + 1 : gamma + 1;
         s_left[i] = left;
         s_right[i] = right;
+        s_lo[i] = (short)lo;
+        s_hi[i] = (short)hi;
         s_parent[left] = i;
         s_parent[right] = i;
     }
     __syncthreads();
-    // ---- bottom-up box fit; the second arrival at a node (LDS atomic) owns it
-    if (i < n && n > 1) {
-        int pnode = s_parent[leaf0 + i];
-        int levels = 1;
-        while (pnode >= 0) {
-            __threadfence_block();
-            if (atomicAdd(&s_visit[pnode], 1) == 0) break;
-            __threadfence_block();
-            const int L = s_left[pnode], R = s_right[pnode];
-            for (int a = 0; a < 3; ++a) {
-                s_nbox[pnode][a] = fminf(s_nbox[L][a], s_nbox[R][a]);
-                s_nbox[pnode][3 + a] = fmaxf(s_nbox[L][3 + a], s_nbox[R][3 + a]);
+    // ---- bottom-up box fit; the second arrival at a node (LDS atomic) owns it.  Run twice: first with the reference's
+    // AABBs (canonical tree, written out), then with tight per-shape boxes and cost weights for the fast walk's tree.
+    auto fit = [&](bool with_weights) {
+        if (i < n && n > 1) {
+            int pnode = s_parent[leaf0 + i];
+            while (pnode >= 0) {
+                __threadfence_block();
+                if (atomicAdd(&s_visit[pnode], 1) == 0) break;
+                __threadfence_block();
+                const int L = s_left[pnode], R = s_right[pnode];
+                for (int a = 0; a < 3; ++a) {
+                    s_nbox[pnode][a] = fminf(s_nbox[L][a], s_nbox[R][a]);
+                    s_nbox[pnode][3 + a] = fmaxf(s_nbox[L][3 + a], s_nbox[R][3 + a]);
+                }
+                if (with_weights) s_wt[pnode] = s_wt[L] + s_wt[R];
+                pnode = s_parent[pnode];
             }
-            pnode = s_parent[pnode];
-            ++levels;
         }
-        (void)levels;
-    }
-    __syncthreads();
-    // ---- depth of every leaf (stack bound) and write-out
+        __syncthreads();
+    };
+    fit(false);
+    // ---- canonical tree: depth of every leaf (stack bound) and write-out
     if (i < n) {
         int dep = 0;
         int q = s_parent[leaf0 + i];
@@ -888,7 +1125,70 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         out_nodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(right));
     }
     __syncthreads();
-    if (i == 0) out_meta[0] = s_depth;
+
+    // ---- fast walk's tree: same topology, TIGHT leaf boxes (the reference's CubeBox boxes are up to 2x oversize per axis,
+    // which only costs OptiX time; any conservative box gives the same closest hit), subtrees collapsed by a cost budget.
+    if (i < n) {
+        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+        const PrimIn P = prims[prim];
+        const float* M = P.M;
+        int wt;
+        for (int a = 0; a < 3; ++a) {
+            const float mx = M[4 * a + 0], my = M[4 * a + 1], mz = M[4 * a + 2], c = M[4 * a + 3];
+            float e;  // half extent of the unit shape's image along world axis a
+            if (P.type == 2) e = 0.5f * fabsf(mx) + 0.5f * fabsf(mz);            // rectangle |x|,|z| <= 1/2, y = 0
+            else if (P.type == 3) e = sqrtf(mx * mx + my * my + mz * mz);          // sphere
+            else if (P.type == 1) e = sqrtf(mx * mx + mz * mz);                    // disk, radius 1 in y = 0
+            else e = sqrtf(mx * mx + mz * mz) + fabsf(my);                         // cylinder, radius 1, |y| <= 1
+            e = e * 1.00001f + 0.001f;  // rounding headroom + the reference's own pad (AABB_EPSILON)
+            s_nbox[leaf0 + i][a] = c - e;
+            s_nbox[leaf0 + i][3 + a] = c + e;
+        }
+        // relative cost of one leaf test vs one box test: rectangles reject on two signs, quadrics need the full transform
+        wt = (P.type == 2) ? 1 : (P.type == 1 ? 4 : 16);
+        s_wt[leaf0 + i] = wt;
+        s_visit[i] = 0;
+    }
+    __syncthreads();
+    fit(true);
+    if (i < n) {
+        // only ancestors that stay internal (cost above the budget) can push on the fast walk's stack
+        int fdep = 0;
+        int q = s_parent[leaf0 + i];
+        while (q >= 0) {
+            if (s_wt[q] > leaf_budget) ++fdep;
+            q = s_parent[q];
+        }
+        atomicMax(&s_fdepth, fdep);
+        // Morton-ordered traversal record of the primitive at sorted position i (its inverse rows were written to out_prims
+        // by the thread owning that primitive, before the barriers above)
+        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+        out_fprims[4 * i + 0] = out_prims[6 * prim + 0];
+        out_fprims[4 * i + 1] = out_prims[6 * prim + 1];
+        out_fprims[4 * i + 2] = out_prims[6 * prim + 2];
+        out_fprims[4 * i + 3] = make_float4(__int_as_float((int)prims[prim].type), __int_as_float(prim), 0.0f, 0.0f);
+    }
+    for (int k = i; k < 2 * n - 1; k += kMaxPrims) {
+        // collapsed leaf = (first Morton position, -count)
+        int fl, fr;
+        if (k >= leaf0) {
+            fl = k - leaf0;
+            fr = -1;
+        } else if (s_wt[k] <= leaf_budget) {
+            fl = s_lo[k];
+            fr = -((int)s_hi[k] - (int)s_lo[k] + 1);
+        } else {
+            fl = s_left[k];
+            fr = s_right[k];
+        }
+        out_fnodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(fl));
+        out_fnodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(fr));
+    }
+    __syncthreads();
+    if (i == 0) {
+        out_meta[0] = s_depth;
+        out_meta[1] = s_fdepth;
+    }
 }
 
 }  // namespace rtgo

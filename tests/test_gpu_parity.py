@@ -103,6 +103,12 @@ def test_all_scenes_small(capi, oracle, name, mode):
     st = ctx.stats()
     for k, tol in (("rays_total", 0.01), ("node_visits", 0.02), ("prim_tests", 0.02), ("hits", 0.01)):
         assert abs(st[k] - rc[k]) <= tol * max(rc[k], 1), (k, st[k], rc[k])
+    # the timed kernel (fast walk over the collapsed LBVH) must give the canonical walk's pixels bit for bit
+    ctx.reset_stats()
+    acc_f, img_f = gpu_render(capi, ctx, W, H, n, 0, path, amb, stats=False)
+    assert np.array_equal(acc_f.view(np.uint32), acc.view(np.uint32)), "fast walk != canonical walk"
+    assert np.array_equal(img_f, img)
+    assert ctx.stats()["rays_total"] == st["rays_total"]
     print(name, mode, m, {k: (st[k], rc[k]) for k in ("rays_total", "node_visits", "prim_tests", "hits")})
 
 
