@@ -21,18 +21,30 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
+def usable_cores():
+    """threads the CPU baseline may really use: the cgroup CPU quota when there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(scene, width, height, sample, path, seconds_cap=30.0):
     """The oracle (scalar C restatement, canonical LBVH, OpenMP over rows) timed on this host's cores: a reported baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
     O.build()
     sc = O.scene(scene, width, height)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     # bounded sample: time a 1/16-area crop first, then the largest centred window expected to fit the cap
     wq, hq = width // 4, height // 4
     win = ((width - wq) // 2, (height - hq) // 2, wq, hq)
     t0 = time.perf_counter()
-    _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, window=win, mode=1))
+    _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, window=win, mode=1, threads=cores))
     dt = time.perf_counter() - t0
     sample_desc = "centre crop %dx%d of frame 0" % (wq, hq)
     rate = c["rays_total"] / dt
@@ -40,7 +52,7 @@ def cpu_baseline(scene, width, height, sample, path, seconds_cap=30.0):
     full_rays_est = width * height * sample * sample * 2.3
     if full_rays_est / rate < seconds_cap * 0.6:
         t0 = time.perf_counter()
-        _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, mode=1))
+        _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, mode=1, threads=cores))
         dt = time.perf_counter() - t0
         sample_desc = "full frame 0 (%dx%d, %d spp)" % (width, height, sample * sample)
     return {"value": round(c["rays_total"] / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",

@@ -39,7 +39,7 @@ struct LightRec {
 struct LaunchParams {
     const float4* nodes;            // canonical LBVH, 2 float4 per node
     const float4* prims;            // 6 float4 per primitive, SBT order
-    const float4* fnodes;           // collapsed LBVH for the fast walk: same indexing, subtrees of <= K primitives are leaves
+    const float4* fnodes;           // collapsed LBVH for the fast walk: same indexing, subtrees whose leaf cost fits the budget are leaves
     const float4* fprims;           // 4 float4 per primitive in Morton order: rows 0..2 of M^-1, (bits(type), bits(SBT index), 0, 0)
     int stack_depth;                // per-lane LDS stack entries this launch needs
     const LightRec* lights;
@@ -319,7 +319,7 @@ __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, 
 // =====================================================================================================================
 // Fast walk (the kernel that is timed).  Same closest hit, bit for bit, as the canonical walk above -- every accepted
 // candidate goes through the same intersection arithmetic and the same acceptance rule -- but organised for the SIMDs:
-//   * LBVH subtrees of <= K primitives are collapsed into one leaf whose primitives sit contiguously (Morton order), so
+//   * LBVH subtrees whose leaf-test cost fits a budget are collapsed into one leaf whose primitives sit contiguously (Morton order), so
 //     a wave spends its time in short uniform primitive loops instead of divergent one-primitive leaves;
 //   * while-while structure: all lanes first descend to their next leaf, then all lanes with a leaf test it;
 //   * the slab test is 6 FMAs on a reciprocal direction (v_rcp_f32): it only steers culling, which stays conservative
