@@ -73,6 +73,9 @@ def main():
     ap.add_argument("--mode", default="path", choices=["path", "distributed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-frame band gather (diagnostic)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="developer rehearsal of the N>1 code path on a 1-GPU box: every rank uses cuda:0 and the gather goes "
+                         "through gloo on host copies. The JSON line is marked and is NOT a measurement.")
     args = ap.parse_args()
 
     import numpy as np
@@ -87,10 +90,16 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
+    rehearse = args.rehearse_on_one_gpu
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     W, H, N = args.width, args.height, args.sample
     path = args.mode == "path"
@@ -120,10 +129,34 @@ def main():
     def frame(f, stats=False):
         return capi.make_frame(W, H, N, f, path, False, None, (band_h, world, rank), stats=stats)
 
+    # N > 1: the 8-bit bands are double-buffered so that the gather of frame f (comm stream -> RCCL) overlaps the
+    # megakernel of frame f+1 (compute stream).  Every frame is still gathered and de-interleaved on rank 0 inside the
+    # timed region; the accumulation buffer is single (frame f+1 reads what frame f wrote, same stream).
+    images = [image, torch.zeros_like(image)] if world > 1 else [image]
+    comm = torch.cuda.Stream(dev) if world > 1 else None
+    gathered = [None, None]   # event: gather that last read images[b] has completed
+
     def step(f):
+        b = f & 1 if world > 1 else 0
+        if world > 1 and gathered[b] is not None:
+            stream.wait_event(gathered[b])            # WAR: do not overwrite a band buffer a gather is still reading
+        ctx.bind_output(accum.data_ptr(), images[b].data_ptr(), rows_pad * W)
         ctx.launch(frame(f))
         if world > 1 and not args.no_gather:
-            bands.gather_bands(image, H, band_h, dist, dst=0, out=full_image, row_index=row_index)
+            done = torch.cuda.Event()
+            done.record(stream)
+            comm.wait_event(done)
+            with torch.cuda.stream(comm):
+                if rehearse:
+                    comm.synchronize()
+                    full = bands.gather_bands(images[b].cpu(), H, band_h, dist, dst=0)
+                    if rank == 0:
+                        full_image.copy_(full)
+                else:
+                    bands.gather_bands(images[b], H, band_h, dist, dst=0, out=full_image, row_index=row_index)
+                ev = torch.cuda.Event()
+                ev.record(comm)
+            gathered[b] = ev
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -137,7 +170,8 @@ def main():
     ctx.launch(frame(args.warmup, stats=True))
     ctx.sync()
     st = ctx.stats()
-    cnt = torch.tensor([st["rays_total"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=dev)
+    rdev = torch.device("cpu") if rehearse else dev   # gloo reduces host tensors
+    cnt = torch.tensor([st["rays_total"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(cnt)
     rays_s, nodes_s, tests_s, hits_s, occl_s = [float(x) for x in cnt.tolist()]
@@ -158,9 +192,9 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     st = ctx.stats()
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    rr = torch.tensor([float(st["rays_total"])], dtype=torch.float64, device=dev)
-    km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
+    rr = torch.tensor([float(st["rays_total"])], dtype=torch.float64, device=rdev)
+    km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1)], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
@@ -183,7 +217,7 @@ def main():
             "config": {"workload": "%s %dx%d --mode=%s --sample=%d (%d spp), progressive frames %d..%d" %
                                    (args.scene, W, H, args.mode, N, N * N, args.warmup, args.warmup + args.steps - 1),
                        "primitives": int(len(t["type"])), "tiling": "4-row bands interleaved over %d GPU(s)" % world,
-                       "gather": "RCCL gather of uchar4 bands to rank 0 per frame" if (world > 1 and not args.no_gather) else "none",
+                       "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (world > 1 and not args.no_gather) else "none",
                        "rays_per_frame": int(round(rays_per_launch))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -194,6 +228,16 @@ def main():
                          "mrays_roofline": round(HBM_PEAK_GBS * 1e3 / A_ray, 1),
                          "note": "algorithmic bytes (SURVEY 8d) per launch / HIP-event kernel time; the scene is LDS-resident so physical HBM traffic is only the framebuffer"},
         }
+        if rehearse:
+            out["rehearsal"] = "all ranks on cuda:0, gloo gather through host memory: NOT a measurement"
+            # correctness of the N>1 path: the gathered 8-bit frame must equal a whole-image render of the same frame
+            whole_a = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+            whole_i = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
+            ctx.bind_output(whole_a.data_ptr(), whole_i.data_ptr(), H * W)
+            for f in range(args.warmup + args.steps):
+                ctx.launch(capi.make_frame(W, H, N, f, path, False, None, (band_h, 1, 0)))
+            ctx.sync()
+            out["rehearsal_frame_matches_single_gpu"] = bool(torch.equal(whole_i, full_image))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scene, W, H, N, path)
         print(json.dumps(out), flush=True)

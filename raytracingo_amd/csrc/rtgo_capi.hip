@@ -39,6 +39,7 @@ struct rtgo_ctx {
     int* d_meta = nullptr;
     int lbvh_depth = 0;
     int fast_depth = 0;
+    int n_small = 0;
     int leaf_budget = kDefaultLeafBudget;
     LightRec* d_lights = nullptr;
     int n_lights = 0;
@@ -98,7 +99,7 @@ const char* rtgo_last_error(const rtgo_ctx* ctx) { return ctx ? ctx->err.c_str()
 uint32_t rtgo_local_rows(uint32_t h, uint32_t band_h, uint32_t n_ranks, uint32_t rank)
 {
     if (n_ranks <= 1) return h;
-    if (band_h == 0) band_h = kTileH;
+    if (band_h == 0) band_h = 4;
     const uint32_t bands = (h + band_h - 1) / band_h;
     uint32_t rows = 0;
     for (uint32_t b = rank; b < bands; b += n_ranks) {
@@ -226,12 +227,13 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), 0, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget, c->d_meta);
     RTGO_HIP(c, hipGetLastError());
-    int meta[2] = {0, 0};
+    int meta[3] = {0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     const int depth = meta[0];
     c->lbvh_depth = depth;
     c->fast_depth = meta[1];
+    c->n_small = meta[2];
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
                                                std::to_string(kStackDepth) + ")");
@@ -327,7 +329,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.w = f->w ? f->w : f->image_width;
     p.h = f->h ? f->h : f->image_height;
     if ((uint64_t)p.x0 + p.w > p.W || (uint64_t)p.y0 + p.h > p.H) return fail(c, RTGO_E_INVALID, "rtgo_launch: window outside the image");
-    p.band_h = f->band_h ? f->band_h : kTileH;
+    p.band_h = f->band_h ? f->band_h : 4;
     p.n_ranks = f->n_ranks ? f->n_ranks : 1;
     p.rank = f->rank;
     if (p.rank >= p.n_ranks) return fail(c, RTGO_E_INVALID, "rtgo_launch: rank >= n_ranks");
@@ -340,6 +342,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.fnodes = c->d_fnodes;
     p.fprims = c->d_fprims;
     const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
+    p.n_small = c->n_small;
     p.stack_depth = stats ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
     p.lights = c->d_lights;
     p.accum = c->d_accum;
@@ -361,7 +364,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim
-    const size_t lds = (size_t)(2 * p.n_nodes + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
+    const int fast_nodes = c->n_small > 0 ? 2 * c->n_small - 1 : 0;
+    const size_t lds = (size_t)(2 * (stats ? p.n_nodes : fast_nodes) + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
                        (size_t)p.stack_depth * kBlock * sizeof(float2) + (size_t)kMaxLights * sizeof(LightRec);
     int blocks_per_cu = (int)((160 * 1024) / lds);
     if (blocks_per_cu < 1) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
@@ -378,10 +382,10 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
-    else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
-    else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds, c->stream, p);
-    else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), lds, c->stream, p);
+    if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
+    else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
+    else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
+    else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
     RTGO_HIP(c, hipGetLastError());
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;

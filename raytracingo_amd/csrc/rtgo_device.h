@@ -16,7 +16,10 @@ namespace rtgo {
 constexpr int kBlock = 256;          // 4 waves per workgroup
 constexpr int kStackDepth = 24;      // per-lane traversal stack entries of the canonical walk (LBVH depth is checked against it at build)
 constexpr int kDefaultLeafBudget = 32;  // fast walk: LBVH subtrees whose leaf-test cost is <= this many rectangle tests become one leaf
-constexpr int kTileW = 16, kTileH = 4;  // one wave = 16x4 pixels: 256-byte float4 rows, 4-row bands for multi-GPU
+#ifndef RTGO_TILE_W
+#define RTGO_TILE_W 16
+#endif
+constexpr int kTileW = RTGO_TILE_W, kTileH = 64 / RTGO_TILE_W;  // one wave = 16x4 pixels: 256-byte float4 rows, 4-row bands for multi-GPU
 constexpr int kMaxPrims = 512;
 constexpr int kMaxLights = 10;
 constexpr int kMaxLevels = 5;        // bounce records kept per path (maxTraceDepth <= 5)
@@ -42,6 +45,7 @@ struct LaunchParams {
     const float4* fnodes;           // collapsed LBVH for the fast walk: same indexing, subtrees whose leaf cost fits the budget are leaves
     const float4* fprims;           // 4 float4 per primitive in Morton order: rows 0..2 of M^-1, (bits(type), bits(SBT index), 0, 0)
     int stack_depth;                // per-lane LDS stack entries this launch needs
+    int n_small;                    // fast walk: fprims [0, n_small) are in the tree, [n_small, n_prims) are tested up front
     const LightRec* lights;
     float4* accum;
     uchar4* image;
@@ -339,7 +343,8 @@ __device__ __forceinline__ bool closer(float t, int orig, float tmin, const Fast
     return t > tmin && (t < best.t || (t == best.t && best.orig >= 0 && orig < best.orig));
 }
 
-__device__ __forceinline__ void leaf_test(const float4* __restrict__ s_fprims, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
+template <typename Ptr>
+__device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
 {
     const float4 r1 = s_fprims[4 * pos + 1];
     const float4 meta = s_fprims[4 * pos + 3];
@@ -455,24 +460,35 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 }
 
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 float2* __restrict__ s_stack, v3 o, v3 d, float tmin, float tmax, Hit& out)
+                                                 const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int n_small,
+                                                 int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out)
 {
     FastHit best;
     best.t = tmax;
     best.nobj = mk(0.0f, 0.0f, 0.0f);
     best.pos = -1;
     best.orig = -1;
-    const v3 id = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
-    float tn;
-    const float4 q0 = s_fnodes[0], q1 = s_fnodes[1];
     out.prim = -1;
     out.t = tmax;
     out.n = mk(0.0f, 0.0f, 0.0f);
-    if (!box_fast(q0, q1, id, noid, tmin, best.t, tn)) return false;
+    // the few "big" primitives (walls, floors; the whole scene when it is tiny) first.  The loop index is wave-uniform and
+    // g_fprims is a read-only kernel argument, so the records arrive by scalar loads (s_load_dwordx4) into SGPRs: no LDS
+    // traffic, no VGPRs for the matrices, and the loads of the next primitives overlap the tests of the current ones.
+    // It also gives every ray a closest-hit bound before it enters the tree.
+#pragma unroll 4
+    for (int k = n_small; k < n_prims; ++k) leaf_test(g_fprims, k, o, d, tmin, best);
+    const v3 id = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
+    float tn;
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0;
+    bool have = n_small > 0;
+    if (have) {
+        q0 = s_fnodes[0];
+        q1 = s_fnodes[1];
+        have = box_fast(q0, q1, id, noid, tmin, best.t, tn);
+    }
     int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
     int sp = 0;
-    bool have = true;
     auto pop = [&]() -> bool {
         while (sp > 0) {
             --sp;
@@ -574,14 +590,15 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v)
 // PATH = Params::enablePathTracing.  STATS adds the V/T/h counters used for the roofline's algorithmic bytes.
 // =====================================================================================================================
 template <bool PATH, bool STATS>
-__global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
+__global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
     //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][stack][lights]
     constexpr int MS = STATS ? 6 : 3;  // float4 stride between two primitives' material rows (kd|spec, kr|type, Le)
+    const int n_nodes = STATS ? p.n_nodes : (p.n_small > 0 ? 2 * p.n_small - 1 : 0);
     float4* s_nodes = reinterpret_cast<float4*>(smem);
-    float4* s_prims = s_nodes + 2 * p.n_nodes;
+    float4* s_prims = s_nodes + 2 * n_nodes;
     float4* s_mat_w = STATS ? s_prims + 3 : s_prims + 4 * p.n_prims;
     float4* s_end = STATS ? s_prims + 6 * p.n_prims : s_mat_w + 3 * p.n_prims;
     float2* s_stack_base = reinterpret_cast<float2*>(s_end);
@@ -594,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
         for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.nodes[i];
         for (int i = tid; i < 6 * p.n_prims; i += kBlock) s_prims[i] = p.prims[i];
     } else {
-        for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.fnodes[i];
+        for (int i = tid; i < 2 * n_nodes; i += kBlock) s_nodes[i] = p.fnodes[i];
         for (int i = tid; i < 4 * p.n_prims; i += kBlock) s_prims[i] = p.fprims[i];
         for (int i = tid; i < 3 * p.n_prims; i += kBlock) s_mat_w[i] = p.prims[6 * (i / 3) + 3 + (i % 3)];
     }
@@ -621,7 +638,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
 
         const unsigned int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
         const unsigned int lx = tx * kTileW + (lane & (kTileW - 1));
-        const unsigned int lr = ty * kTileH + (lane >> 4);  // local (compact) row
+        const unsigned int lr = ty * kTileH + (lane / kTileW);  // local (compact) row
         const bool in_range = lx < p.w && lr < p.local_rows;
         // local row -> window row under the band interleave
         const unsigned int band = lr / p.band_h;
@@ -677,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p)
                 c_rays += 1;
                 bool hit;
                 if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h);
+                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, p.n_small, p.n_prims, ro, rd, tmin, tmax, h);
                 if (STATS && hit) c_hits += 1;
 
                 bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
@@ -954,33 +971,139 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
     return __clz(a ^ b);
 }
 
-// out_nodes: (2n-1) x 2 float4; out_prims: n x 6 float4; aabb_io: n x 6 floats (read when have_aabb, else written);
-// out_meta[0] = tree depth (levels below the root that a traversal stack may need)
+// Outputs.  out_nodes: (2n-1) x 2 float4 canonical LBVH; out_prims: n x 6 float4 (SBT order); aabb_io: n x 6 floats (read when
+// have_aabb, else written); out_fnodes / out_fprims: the fast walk's tree (2*n_small-1 nodes) and Morton-ordered records
+// (small primitives first, then the "big" ones that are tested up front);
+// out_meta = {canonical depth, fast-walk stack depth, n_small}.
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
                                                           float4* __restrict__ out_fprims, int leaf_budget, int* __restrict__ out_meta)
 {
-    __shared__ float s_box[kMaxPrims][6];
+    __shared__ float s_box[kMaxPrims][6];               // per primitive: reference AABB, later the tight box
     __shared__ unsigned long long s_keys[kMaxPrims];
     __shared__ float s_nbox[2 * kMaxPrims][6];
     __shared__ int s_left[kMaxPrims], s_right[kMaxPrims];
     __shared__ int s_parent[2 * kMaxPrims];
     __shared__ int s_visit[kMaxPrims];
-    __shared__ int s_wt[2 * kMaxPrims];  // fast walk: cost weight of each subtree
+    __shared__ int s_wt[2 * kMaxPrims];                 // fast walk: cost weight of each subtree
     __shared__ short s_lo[kMaxPrims], s_hi[kMaxPrims];  // Morton range covered by each internal node
-    __shared__ int s_depth, s_fdepth;
-    // the bounds reduction runs before s_nbox is first written: reuse its storage (keeps static LDS under 64 KiB)
+    __shared__ unsigned char s_flag[kMaxPrims];         // fast walk: 1 = "big" primitive kept out of the tree
+    __shared__ int s_depth, s_count;
+    // the bounds reductions run while s_nbox is not in use: borrow its storage (keeps static LDS under 64 KiB)
     float(*s_red)[kMaxPrims] = reinterpret_cast<float(*)[kMaxPrims]>(&s_nbox[0][0]);
 
     const int i = threadIdx.x;
+
+    // min/max over the boxes of the primitives selected by `take` -> s_red[0..5][0] (exact, order-independent)
+    auto reduce_bounds = [&](bool take) {
+        for (int a = 0; a < 3; ++a) {
+            s_red[a][i] = take ? s_box[i][a] : INFINITY;
+            s_red[3 + a][i] = take ? s_box[i][3 + a] : -INFINITY;
+        }
+        __syncthreads();
+        for (int stride = kMaxPrims / 2; stride > 0; stride >>= 1) {
+            if (i < stride)
+                for (int a = 0; a < 3; ++a) {
+                    s_red[a][i] = fminf(s_red[a][i], s_red[a][i + stride]);
+                    s_red[3 + a][i] = fmaxf(s_red[3 + a][i], s_red[3 + a][i + stride]);
+                }
+            __syncthreads();
+        }
+    };
+    // 30-bit Morton code of primitive i's box centre normalised to the bounds in s_red[..][0]
+    auto morton_of = [&]() -> unsigned int {
+        unsigned int q[3];
+        for (int a = 0; a < 3; ++a) {
+            const float c = (s_box[i][a] + s_box[i][3 + a]) * 0.5f;
+            const float ext = s_red[3 + a][0] - s_red[a][0];
+            const float u = ext > 0.0f ? (c - s_red[a][0]) / ext : 0.0f;
+            q[a] = (unsigned int)fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
+        }
+        return (expand_bits(q[0]) << 2) | (expand_bits(q[1]) << 1) | expand_bits(q[2]);
+    };
+    // bitonic sort of the kMaxPrims keys in LDS; keys are unique, so the result is THE (code, index) order
+    auto sort_keys = [&]() {
+        __syncthreads();
+        for (int k = 2; k <= kMaxPrims; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s_keys[i], b = s_keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        s_keys[i] = b;
+                        s_keys[ixj] = a;
+                    }
+                }
+                __syncthreads();
+            }
+    };
+    // Karras 2012 over the first m sorted keys + bottom-up fit of boxes (and cost weights).  Leaves are nodes [m-1, 2m-2].
+    auto build_tree = [&](int m, bool with_weights) {
+        const int leaf0 = m - 1;
+        if (i < m) {
+            const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+            for (int a = 0; a < 6; ++a) s_nbox[leaf0 + i][a] = s_box[prim][a];
+            s_visit[i] = 0;
+        }
+        if (i < 2 * m - 1) s_parent[i] = -1;
+        if (i + kMaxPrims < 2 * m - 1) s_parent[i + kMaxPrims] = -1;
+        __syncthreads();
+        if (i < m - 1) {
+            const int d = (lbvh_delta(s_keys, m, i, i + 1) - lbvh_delta(s_keys, m, i, i - 1)) >= 0 ? 1 : -1;
+            const int dmin = lbvh_delta(s_keys, m, i, i - d);
+            int lmax = 2;
+            while (lbvh_delta(s_keys, m, i, i + lmax * d) > dmin) lmax *= 2;
+            int l = 0;
+            for (int t = lmax / 2; t >= 1; t /= 2)
+                if (lbvh_delta(s_keys, m, i, i + (l + t) * d) > dmin) l += t;
+            const int j = i + l * d;
+            const int dnode = lbvh_delta(s_keys, m, i, j);
+            int s = 0, t = l;
+            do {
+                t = (t + 1) / 2;
+                if (lbvh_delta(s_keys, m, i, i + (s + t) * d) > dnode) s += t;
+            } while (t > 1);
+            const int gamma = i + s * d + (d < 0 ? -1 : 0);
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int left = (lo == gamma) ? leaf0 + gamma : gamma;
+            const int right = (hi == gamma + 1) ? leaf0 + gamma + 1 : gamma + 1;
+            s_left[i] = left;
+            s_right[i] = right;
+            s_lo[i] = (short)lo;
+            s_hi[i] = (short)hi;
+            s_parent[left] = i;
+            s_parent[right] = i;
+        }
+        __syncthreads();
+        // the second arrival at a node (LDS atomic) owns it
+        if (i < m && m > 1) {
+            int pnode = s_parent[leaf0 + i];
+            while (pnode >= 0) {
+                __threadfence_block();
+                if (atomicAdd(&s_visit[pnode], 1) == 0) break;
+                __threadfence_block();
+                const int L = s_left[pnode], R = s_right[pnode];
+                for (int a = 0; a < 3; ++a) {
+                    s_nbox[pnode][a] = fminf(s_nbox[L][a], s_nbox[R][a]);
+                    s_nbox[pnode][3 + a] = fmaxf(s_nbox[L][3 + a], s_nbox[R][3 + a]);
+                }
+                if (with_weights) s_wt[pnode] = s_wt[L] + s_wt[R];
+                pnode = s_parent[pnode];
+            }
+        }
+        __syncthreads();
+    };
+
     if (i == 0) {
         s_depth = 0;
-        s_fdepth = 0;
+        s_count = 0;
     }
-    // ---- per primitive: inverse, record, AABB
+    // ---- per primitive: inverse, record, reference AABB
+    PrimIn P;
     if (i < n) {
-        const PrimIn P = prims[i];
+        P = prims[i];
         float inv[12];
         inverse_rows012(P.M, inv);
         out_prims[6 * i + 0] = make_float4(inv[0], inv[1], inv[2], inv[3]);
@@ -998,196 +1121,126 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         }
         for (int a = 0; a < 6; ++a) s_box[i][a] = bb[a];
     }
-    // ---- scene bounds (min/max are exact: any reduction order gives the same value)
-    for (int a = 0; a < 3; ++a) {
-        s_red[a][i] = (i < n) ? s_box[i][a] : INFINITY;
-        s_red[3 + a][i] = (i < n) ? s_box[i][3 + a] : -INFINITY;
-    }
-    __syncthreads();
-    for (int stride = kMaxPrims / 2; stride > 0; stride >>= 1) {
-        if (i < stride)
-            for (int a = 0; a < 3; ++a) {
-                s_red[a][i] = fminf(s_red[a][i], s_red[a][i + stride]);
-                s_red[3 + a][i] = fmaxf(s_red[3 + a][i], s_red[3 + a][i + stride]);
-            }
-        __syncthreads();
-    }
-    // ---- Morton keys: (30-bit code << 32) | primitive index; padding keys sort last
-    {
-        unsigned long long key = ~0ull;
-        if (i < n) {
-            unsigned int q[3];
-            for (int a = 0; a < 3; ++a) {
-                const float c = (s_box[i][a] + s_box[i][3 + a]) * 0.5f;
-                const float ext = s_red[3 + a][0] - s_red[a][0];
-                const float u = ext > 0.0f ? (c - s_red[a][0]) / ext : 0.0f;
-                q[a] = (unsigned int)fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
-            }
-            const unsigned int code = (expand_bits(q[0]) << 2) | (expand_bits(q[1]) << 1) | expand_bits(q[2]);
-            key = ((unsigned long long)code << 32) | (unsigned int)i;
-        }
-        s_keys[i] = key;
-    }
-    __syncthreads();
-    // ---- bitonic sort of kMaxPrims keys in LDS (keys are unique, so the order is the (code, index) order)
-    for (int k = 2; k <= kMaxPrims; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const int ixj = i ^ j;
-            if (ixj > i) {
-                const unsigned long long a = s_keys[i], b = s_keys[ixj];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) {
-                    s_keys[i] = b;
-                    s_keys[ixj] = a;
-                }
-            }
-            __syncthreads();
-        }
-    // ---- leaves
-    const int leaf0 = n - 1;
-    if (i < n) {
-        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
-        for (int a = 0; a < 6; ++a) s_nbox[leaf0 + i][a] = s_box[prim][a];
-    }
-    if (i < 2 * n - 1) s_parent[i] = -1;
-    if (i + kMaxPrims < 2 * n - 1) s_parent[i + kMaxPrims] = -1;
-    if (i < n) s_visit[i] = 0;
-    __syncthreads();
-    // ---- Karras 2012 internal nodes
-    if (i < n - 1) {
-        const int d = (lbvh_delta(s_keys, n, i, i + 1) - lbvh_delta(s_keys, n, i, i - 1)) >= 0 ? 1 : -1;
-        const int dmin = lbvh_delta(s_keys, n, i, i - d);
-        int lmax = 2;
-        while (lbvh_delta(s_keys, n, i, i + lmax * d) > dmin) lmax *= 2;
-        int l = 0;
-        for (int t = lmax / 2; t >= 1; t /= 2)
-            if (lbvh_delta(s_keys, n, i, i + (l + t) * d) > dmin) l += t;
-        const int j = i + l * d;
-        const int dnode = lbvh_delta(s_keys, n, i, j);
-        int s = 0, t = l;
-        do {
-            t = (t + 1) / 2;
-            if (lbvh_delta(s_keys, n, i, i + (s + t) * d) > dnode) s += t;
-        } while (t > 1);
-        const int gamma = i + s * d + (d < 0 ? -1 : 0);
-        const int lo = i < j ? i : j, hi = i < j ? j : i;
-        const int left = (lo == gamma) ? leaf0 + gamma : gamma;
-        const int right = (hi == gamma + 1) ? leaf0 + gamma + 1 : gamma + 1;
-        s_left[i] = left;
-        s_right[i] = right;
-        s_lo[i] = (short)lo;
-        s_hi[i] = (short)hi;
-        s_parent[left] = i;
-        s_parent[right] = i;
-    }
-    __syncthreads();
-    // ---- bottom-up box fit; the second arrival at a node (LDS atomic) owns it.  Run twice: first with the reference's
-    // AABBs (canonical tree, written out), then with tight per-shape boxes and cost weights for the fast walk's tree.
-    auto fit = [&](bool with_weights) {
-        if (i < n && n > 1) {
-            int pnode = s_parent[leaf0 + i];
-            while (pnode >= 0) {
-                __threadfence_block();
-                if (atomicAdd(&s_visit[pnode], 1) == 0) break;
-                __threadfence_block();
-                const int L = s_left[pnode], R = s_right[pnode];
-                for (int a = 0; a < 3; ++a) {
-                    s_nbox[pnode][a] = fminf(s_nbox[L][a], s_nbox[R][a]);
-                    s_nbox[pnode][3 + a] = fmaxf(s_nbox[L][3 + a], s_nbox[R][3 + a]);
-                }
-                if (with_weights) s_wt[pnode] = s_wt[L] + s_wt[R];
-                pnode = s_parent[pnode];
-            }
-        }
-        __syncthreads();
-    };
-    fit(false);
-    // ---- canonical tree: depth of every leaf (stack bound) and write-out
-    if (i < n) {
-        int dep = 0;
-        int q = s_parent[leaf0 + i];
-        while (q >= 0) {
-            ++dep;
-            q = s_parent[q];
-        }
-        atomicMax(&s_depth, dep);
-    }
-    for (int k = i; k < 2 * n - 1; k += kMaxPrims) {
-        int left, right;
-        if (k >= leaf0) {
-            left = (int)(s_keys[k - leaf0] & 0xFFFFFFFFu);
-            right = -1;
-        } else {
-            left = s_left[k];
-            right = s_right[k];
-        }
-        out_nodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(left));
-        out_nodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(right));
-    }
     __syncthreads();
 
-    // ---- fast walk's tree: same topology, TIGHT leaf boxes (the reference's CubeBox boxes are up to 2x oversize per axis,
-    // which only costs OptiX time; any conservative box gives the same closest hit), subtrees collapsed by a cost budget.
+    // ================= canonical LBVH: every primitive, the reference's AABBs =================
+    reduce_bounds(i < n);
+    s_keys[i] = (i < n) ? (((unsigned long long)morton_of() << 32) | (unsigned int)i) : ~0ull;
+    sort_keys();
+    build_tree(n, false);
+    {
+        const int leaf0 = n - 1;
+        if (i < n) {
+            int dep = 0;
+            int q = s_parent[leaf0 + i];
+            while (q >= 0) {
+                ++dep;
+                q = s_parent[q];
+            }
+            atomicMax(&s_depth, dep);
+        }
+        for (int k = i; k < 2 * n - 1; k += kMaxPrims) {
+            int left, right;
+            if (k >= leaf0) {
+                left = (int)(s_keys[k - leaf0] & 0xFFFFFFFFu);
+                right = -1;
+            } else {
+                left = s_left[k];
+                right = s_right[k];
+            }
+            out_nodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(left));
+            out_nodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(right));
+        }
+    }
+    __syncthreads();
+    if (i == 0) out_meta[0] = s_depth;
+
+    // ================= fast walk's structure =================
+    // Any conservative structure returns the same closest hit, so this one is built for speed:
+    //  * TIGHT per-shape boxes (the reference's CubeBox boxes are up to 2x oversize per axis);
+    //  * "big" primitives (box spanning >= 40 % of the scene on two axes: room walls, floors) stay out of the tree and are
+    //    tested first, which also gives every ray an early closest-hit bound for culling the tree;
+    //  * LBVH over the rest, subtrees collapsed into multi-primitive leaves by a cost budget.
     if (i < n) {
-        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
-        const PrimIn P = prims[prim];
         const float* M = P.M;
-        int wt;
         for (int a = 0; a < 3; ++a) {
             const float mx = M[4 * a + 0], my = M[4 * a + 1], mz = M[4 * a + 2], c = M[4 * a + 3];
             float e;  // half extent of the unit shape's image along world axis a
-            if (P.type == 2) e = 0.5f * fabsf(mx) + 0.5f * fabsf(mz);            // rectangle |x|,|z| <= 1/2, y = 0
-            else if (P.type == 3) e = sqrtf(mx * mx + my * my + mz * mz);          // sphere
-            else if (P.type == 1) e = sqrtf(mx * mx + mz * mz);                    // disk, radius 1 in y = 0
-            else e = sqrtf(mx * mx + mz * mz) + fabsf(my);                         // cylinder, radius 1, |y| <= 1
+            if (P.type == 2) e = 0.5f * fabsf(mx) + 0.5f * fabsf(mz);   // rectangle |x|,|z| <= 1/2, y = 0
+            else if (P.type == 3) e = sqrtf(mx * mx + my * my + mz * mz);  // sphere
+            else if (P.type == 1) e = sqrtf(mx * mx + mz * mz);            // disk, radius 1 in y = 0
+            else e = sqrtf(mx * mx + mz * mz) + fabsf(my);                 // cylinder, radius 1, |y| <= 1
             e = e * 1.00001f + 0.001f;  // rounding headroom + the reference's own pad (AABB_EPSILON)
-            s_nbox[leaf0 + i][a] = c - e;
-            s_nbox[leaf0 + i][3 + a] = c + e;
+            s_box[i][a] = c - e;
+            s_box[i][3 + a] = c + e;
         }
-        // relative cost of one leaf test vs one box test: rectangles reject on two signs, quadrics need the full transform
-        wt = (P.type == 2) ? 1 : (P.type == 1 ? 4 : 16);
-        s_wt[leaf0 + i] = wt;
-        s_visit[i] = 0;
     }
     __syncthreads();
-    fit(true);
+    reduce_bounds(i < n);
+    bool big = false;
     if (i < n) {
-        // only ancestors that stay internal (cost above the budget) can push on the fast walk's stack
-        int fdep = 0;
-        int q = s_parent[leaf0 + i];
-        while (q >= 0) {
-            if (s_wt[q] > leaf_budget) ++fdep;
-            q = s_parent[q];
-        }
-        atomicMax(&s_fdepth, fdep);
-        // Morton-ordered traversal record of the primitive at sorted position i (its inverse rows were written to out_prims
-        // by the thread owning that primitive, before the barriers above)
-        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
-        out_fprims[4 * i + 0] = out_prims[6 * prim + 0];
-        out_fprims[4 * i + 1] = out_prims[6 * prim + 1];
-        out_fprims[4 * i + 2] = out_prims[6 * prim + 2];
-        out_fprims[4 * i + 3] = make_float4(__int_as_float((int)prims[prim].type), __int_as_float(prim), 0.0f, 0.0f);
+        int wide = 0;
+        for (int a = 0; a < 3; ++a)
+            if (s_box[i][3 + a] - s_box[i][a] >= 0.4f * (s_red[3 + a][0] - s_red[a][0])) ++wide;
+        big = wide >= 2;
+        s_flag[i] = big ? 1 : 0;
+        if (!big) atomicAdd(&s_count, 1);
     }
-    for (int k = i; k < 2 * n - 1; k += kMaxPrims) {
-        // collapsed leaf = (first Morton position, -count)
-        int fl, fr;
-        if (k >= leaf0) {
-            fl = k - leaf0;
-            fr = -1;
-        } else if (s_wt[k] <= leaf_budget) {
-            fl = s_lo[k];
-            fr = -((int)s_hi[k] - (int)s_lo[k] + 1);
-        } else {
-            fl = s_left[k];
-            fr = s_right[k];
+    __syncthreads();
+    const int n_small = s_count;
+    reduce_bounds(i < n && !big);
+    // small primitives sort by Morton code; big ones after them, in SBT order
+    s_keys[i] = (i < n) ? ((big ? (0xFFFFFFFEull << 32) : ((unsigned long long)morton_of() << 32)) | (unsigned int)i) : ~0ull;
+    sort_keys();
+    if (i < n_small) {
+        const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+        const unsigned int type = prims[prim].type;
+        // relative cost of one leaf test vs one box test: rectangles reject on two signs, quadrics need the full transform
+        s_wt[n_small - 1 + i] = (type == 2) ? 1 : (type == 1 ? 4 : 32);
+    }
+    if (i == 0) s_depth = 0;
+    __syncthreads();
+    if (n_small > 0) build_tree(n_small, true);
+    {
+        const int leaf0 = n_small - 1;
+        if (i < n_small) {
+            // only ancestors that stay internal (cost above the budget) can push on the fast walk's stack
+            int fdep = 0;
+            int q = s_parent[leaf0 + i];
+            while (q >= 0) {
+                if (s_wt[q] > leaf_budget) ++fdep;
+                q = s_parent[q];
+            }
+            atomicMax(&s_depth, fdep);
         }
-        out_fnodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(fl));
-        out_fnodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(fr));
+        if (i < n) {
+            // Morton-ordered traversal record (inverse rows were written to out_prims by the primitive's own thread above)
+            const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+            out_fprims[4 * i + 0] = out_prims[6 * prim + 0];
+            out_fprims[4 * i + 1] = out_prims[6 * prim + 1];
+            out_fprims[4 * i + 2] = out_prims[6 * prim + 2];
+            out_fprims[4 * i + 3] = make_float4(__int_as_float((int)prims[prim].type), __int_as_float(prim), 0.0f, 0.0f);
+        }
+        for (int k = i; k < 2 * n_small - 1; k += kMaxPrims) {
+            int fl, fr;  // collapsed leaf = (first Morton position, -count)
+            if (k >= leaf0) {
+                fl = k - leaf0;
+                fr = -1;
+            } else if (s_wt[k] <= leaf_budget) {
+                fl = s_lo[k];
+                fr = -((int)s_hi[k] - (int)s_lo[k] + 1);
+            } else {
+                fl = s_left[k];
+                fr = s_right[k];
+            }
+            out_fnodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(fl));
+            out_fnodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(fr));
+        }
     }
     __syncthreads();
     if (i == 0) {
-        out_meta[0] = s_depth;
-        out_meta[1] = s_fdepth;
+        out_meta[1] = s_depth;
+        out_meta[2] = n_small;
     }
 }
 

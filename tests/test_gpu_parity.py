@@ -171,3 +171,76 @@ def test_error_behaviour(capi, oracle):
         ctx2.launch(capi.make_frame(64, 64, window=(10, 10, 64, 64)))
     with pytest.raises(capi.RtgoError):
         ctx.set_scene(np.zeros(0, np.int32), np.zeros((0, 16), np.float32), np.zeros((0, 10), np.float32))
+
+
+def test_config3_balls_1080p_properties(capi, oracle):
+    """BASELINE config 3 size (balls 1920x1080 path N=4): determinism + crop vs oracle at full scale"""
+    W, H, n = 1920, 1080, 4
+    sc, t, ctx = upload(capi, oracle, "balls", W, H)
+    acc, img = gpu_render(capi, ctx, W, H, n, 0, True)
+    st = ctx.stats()
+    assert np.isfinite(acc).all() and 16 * W * H <= st["rays_total"] <= 6 * 16 * W * H
+    assert np.array_equal((np.clip(acc[..., :3], 0.0, 1.0) * np.float32(255.0)).astype(np.uint8), img[..., :3])
+    win = (900, 500, 160, 90)
+    racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, window=win, mode=1))
+    assert_parity(acc[500:590, 900:1060], racc, img[500:590, 900:1060], rimg, what="balls 1080p crop")
+
+
+def test_config4_mirror_spheres_4k_bands_of_8(capi, oracle):
+    """BASELINE config 4 geometry (mirror_spheres 3840x2160, framebuffer tiled over 8 ranks) on one GPU: the 8 band
+    launches reassemble to the whole-image launch bit for bit (N=2 here to keep the test short; N is not part of the tiling)"""
+    W, H, n = 3840, 2160, 2
+    sc, t, ctx = upload(capi, oracle, "mirror_spheres", W, H)
+    full, fimg = gpu_render(capi, ctx, W, H, n, 0, True)
+    out = np.zeros_like(full)
+    rays = 0
+    total = ctx.stats()["rays_total"]
+    ctx.reset_stats()
+    for g in range(8):
+        a, _ = gpu_render(capi, ctx, W, H, n, 0, True, bands=(4, 8, g))
+        out[[r for r in range(H) if (r // 4) % 8 == g]] = a
+    assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
+    assert ctx.stats()["rays_total"] == total          # the 8 bands trace exactly the rays of the whole frame
+    win = (1800, 1000, 128, 72)
+    racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, window=win, mode=1))
+    assert_parity(full[1000:1072, 1800:1928], racc, what="mirror_spheres 4K crop")
+
+
+def test_config5_plateau_progressive_deep(capi, oracle):
+    """BASELINE config 5 shape (plateau, N=16 = 256 spp, progressive frames) at reduced resolution: 4 accumulated frames"""
+    W, H, n = 96, 54, 16
+    sc, t, ctx = upload(capi, oracle, "plateau", W, H)
+    racc = None
+    for f in range(3):
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, f, path=True, mode=1), accum_prev=racc)
+        acc, img = gpu_render(capi, ctx, W, H, n, f, True)
+    assert_parity(acc, racc, img, rimg, what="plateau N=16 frames 0-2")
+
+
+def test_host_renderer_end_to_end(capi, oracle):
+    """the C++ engine::host::Renderer (headless Display loop) over the ABI == the oracle, and == driving the ABI from Python"""
+    from raytracingo_amd import scene as hscene
+    W, H = 96, 64
+    acc, img, st = hscene.host_render("cornell", "path", W, H, sample=2, frames=3)
+    sc = oracle.scene("cornell", W, H)
+    racc = None
+    for f in range(3):
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, 2, f, path=True, mode=1), accum_prev=racc)
+    assert_parity(acc, racc, img, rimg, what="host Renderer")
+    assert st["launches"] == 3
+    acc2, img2, _ = hscene.host_render("window", "distributed", W, H, sample=1, ambient=True, frames=1)
+    r2, i2, _ = oracle.render(oracle.scene("window", W, H), oracle.frame(W, H, 1, 0, path=False, ambient=True, mode=1))
+    assert_parity(acc2, r2, img2, i2, min_frac=0.985, what="host Renderer distributed+ambient")
+
+
+def test_golden_oracle_renders(capi, oracle):
+    """committed fixtures (tests/golden/oracle_renders.npz): the GPU against stored oracle output, no oracle run needed"""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_renders.npz"))
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_renders.json")) as f:
+        meta = json.load(f)["cases"]
+    for i, m in enumerate(meta):
+        sc, t, ctx = upload(capi, oracle, m["name"], m["W"], m["H"])
+        for fr in range(m["frames"]):
+            acc, img = gpu_render(capi, ctx, m["W"], m["H"], m["N"], fr, m["path"], m["ambient"])
+        assert_parity(acc, z["accum_%d" % i], img, z["image_%d" % i], min_frac=0.985, what=str(m))
+        ctx.close()
