@@ -21,6 +21,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 
 
+def pmc_traffic(scene, W, H, mode, N):
+    """HBM bytes per launch from the newest committed PMC profile of this workload (profiles/*/summary.json, produced by
+    tools/profile_round.sh with separate --pmc passes for FETCH_SIZE and WRITE_SIZE); None when there is none."""
+    import glob
+    best = None
+    key = "%s %dx%d --mode=%s --sample=%d" % (scene, W, H, mode, N)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
+        try:
+            j = json.load(open(f))
+            if key in j["bench"]["config"]["workload"] and "hbm_traffic_bytes_per_launch" in j:
+                best = (j["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+        except Exception:
+            pass
+    return best
+
+
 def usable_cores():
     """threads the CPU baseline may really use: the cgroup CPU quota when there is one, else the affinity mask"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -204,6 +220,7 @@ def main():
     kernel_ms = float(km.item())          # slowest rank's average megakernel duration (HIP events on the launch stream)
 
     if rank == 0:
+        traffic = pmc_traffic(args.scene, W, H, args.mode, N)
         ms_per_step = dt / args.steps * 1e3
         mrays = rays_total / dt / 1e6
         rays_per_launch = rays_total / args.steps
@@ -220,7 +237,10 @@ def main():
                        "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (world > 1 and not args.no_gather) else "none",
                        "rays_per_frame": int(round(rays_per_launch))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": (round(traffic[0]) if traffic and world == 1 else None),
+                         "traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE+WRITE_SIZE)*1024",
+                         "traffic_source": (traffic[1] if traffic and world == 1 else None),
                          "kernel": "rtgo::render_kernel<%s,false>" % ("true" if path else "false"),
                          "kernel_ms": round(kernel_ms, 4), "A_ray_bytes": round(A_ray, 1), "A_px_bytes": A_px,
                          "V": round(Vbar, 3), "T": round(Tbar, 3), "h": round(hbar, 4),
