@@ -539,6 +539,14 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     return true;
 }
 
+// acos(pow(base, expo)) with both steps in f64, each rounded to float like the reference's float calls.  Kept out of line:
+// the f64 libm bodies need ~80 VGPRs that would otherwise be charged to every wave of the megakernel.
+__device__ __attribute__((noinline)) float glossy_theta(float base, float expo)
+{
+    const float c = (float)pow((double)base, (double)expo);
+    return (float)acos((double)c);
+}
+
 // GetRayOnHemisphere, kernel.cu:101-122
 __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed)
 {
@@ -560,8 +568,7 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
             // glossy lobe: acos(pow(x, 1/(coef+1))) sits at the ill-conditioned end of acos (argument within 1e-4 of 1),
             // where one ulp of pow moves theta by ~1e-3 relative.  Evaluate both in f64 and round, which reproduces a
             // correctly rounded float libm (tools/libm_probe: <0.02 % differing results vs 12 % / 28 % for the f32 forms).
-            const float c = (float)pow((double)base, (double)expo);
-            theta = (float)acos((double)c);
+            theta = glossy_theta(base, expo);
         }
         float st, ct, sp, cp;
         st = sinf(theta);
@@ -672,7 +679,14 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p, co
         bool sNVneg = false;
 
         while (__ballot(alive) != 0ull) {
-            if (alive && !in_path) {
+#ifndef RTGO_REGEN_THRESHOLD
+#define RTGO_REGEN_THRESHOLD 16
+#endif
+            // lanes whose path has ended wait until at least RTGO_REGEN_THRESHOLD lanes are waiting (1 = regenerate at once)
+            const int waiting = __popcll(__ballot(alive && !in_path));
+            const int running = __popcll(__ballot(alive && in_path));
+            const bool regen = waiting >= RTGO_REGEN_THRESHOLD || running == 0;
+            if (regen && alive && !in_path) {
                 // start sample s: kernel.cu:206-231.  i-major order, x jitter drawn first
                 const unsigned int i = s / (unsigned int)p.sqrt_spp, j = s - i * (unsigned int)p.sqrt_spp;
                 const float r0 = rnd(pix_seed);
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p, co
                 in_path = true;
                 ++s;
             }
-            if (alive) {
+            if (alive && in_path) {
                 Hit h;
                 c_rays += 1;
                 bool hit;
