@@ -363,15 +363,29 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.bg = c->bg;
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
-    // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim
+    // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
+    // The scene copy is per workgroup and the stack per lane, so bigger scenes want bigger workgroups: pick the size that
+    // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
     const int fast_nodes = c->n_small > 0 ? 2 * c->n_small - 1 : 0;
-    const size_t lds = (size_t)(2 * (stats ? p.n_nodes : fast_nodes) + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
-                       (size_t)p.stack_depth * kBlock * sizeof(float2) + (size_t)kMaxLights * sizeof(LightRec);
-    int blocks_per_cu = (int)((160 * 1024) / lds);
-    if (blocks_per_cu < 1) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
-    if (blocks_per_cu > 4) blocks_per_cu = 4;  // 16 waves per CU = 4 per SIMD is what the kernel's VGPR budget admits
+    const size_t scene_lds = (size_t)(2 * (stats ? p.n_nodes : fast_nodes) + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
+                             (size_t)kMaxLights * sizeof(LightRec);
+    int block = 0, blocks_per_cu = 0, best_waves = 0;
+    size_t lds = 0;
+    for (int b = 256; b <= kMaxBlock; b *= 2) {
+        const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2);
+        int per_cu = (int)((160 * 1024) / l);
+        if (per_cu * (b / 64) > 16) per_cu = 16 / (b / 64);
+        const int waves = per_cu * (b / 64);
+        if (waves > best_waves) {
+            best_waves = waves;
+            block = b;
+            blocks_per_cu = per_cu;
+            lds = l;
+        }
+    }
+    if (best_waves == 0) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
     unsigned int grid = (unsigned int)(c->num_cus * blocks_per_cu);
-    const unsigned int need = (p.n_tiles + (kBlock / 64) - 1) / (kBlock / 64);
+    const unsigned int need = (p.n_tiles + (block / 64) - 1) / (block / 64);
     if (grid > need) grid = need;
 
     RTGO_HIP(c, hipSetDevice(c->device));
@@ -382,10 +396,10 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
-    else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
-    else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
-    else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kBlock), lds, c->stream, p, (const float4*)c->d_fprims);
+    if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
+    else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
+    else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
+    else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
     RTGO_HIP(c, hipGetLastError());
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;

@@ -13,7 +13,7 @@
 
 namespace rtgo {
 
-constexpr int kBlock = 256;          // 4 waves per workgroup
+constexpr int kMaxBlock = 1024;      // workgroup = 256, 512 or 1024 threads: chosen per scene so that 16 waves fit a CU's LDS
 constexpr int kStackDepth = 24;      // per-lane traversal stack entries of the canonical walk (LBVH depth is checked against it at build)
 constexpr int kDefaultLeafBudget = 32;  // fast walk: LBVH subtrees whose leaf-test cost is <= this many rectangle tests become one leaf
 #ifndef RTGO_TILE_W
@@ -240,7 +240,7 @@ struct Hit {
 // tmin < t < current tmax; ties keep the lower SBT index.
 template <bool STATS>
 __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, const float4* __restrict__ s_prims,
-                                            float2* __restrict__ s_stack, v3 o, v3 d, float tmin, float tmax, Hit& best,
+                                            float2* __restrict__ s_stack, int bshift, v3 o, v3 d, float tmin, float tmax, Hit& best,
                                             unsigned int& c_nodes, unsigned int& c_tests)
 {
     best.prim = -1;
@@ -281,7 +281,7 @@ __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, 
                 // push the far child
                 const int far_idx = swap ? left : right;
                 const float far_t = swap ? tl : tr;
-                s_stack[sp * kBlock] = make_float2(far_t, __int_as_float(far_idx));
+                s_stack[sp << bshift] = make_float2(far_t, __int_as_float(far_idx));
                 ++sp;
                 if (swap) {
                     left = __float_as_int(h0.w);
@@ -304,7 +304,7 @@ __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, 
             bool found = false;
             while (sp > 0) {
                 --sp;
-                const float2 e = s_stack[sp * kBlock];
+                const float2 e = s_stack[sp << bshift];
                 if (e.x <= best.t) {
                     const int idx = __float_as_int(e.y);
                     const float4 n0 = s_nodes[2 * idx], n1 = s_nodes[2 * idx + 1];
@@ -460,8 +460,8 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 }
 
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int n_small,
-                                                 int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out)
+                                                 const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int bshift,
+                                                 int n_small, int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out)
 {
     FastHit best;
     best.t = tmax;
@@ -492,7 +492,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     auto pop = [&]() -> bool {
         while (sp > 0) {
             --sp;
-            const float2 e = s_stack[sp * kBlock];
+            const float2 e = s_stack[sp << bshift];
             if (e.x <= best.t) {
                 const int idx = __float_as_int(e.y);
                 left = __float_as_int(s_fnodes[2 * idx].w);
@@ -511,7 +511,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
             const bool hr = box_fast(h0, h1, id, noid, tmin, best.t, tr);
             if (hl && hr) {
                 const bool swap = tr < tl;
-                s_stack[sp * kBlock] = make_float2(swap ? tl : tr, __int_as_float(swap ? left : right));
+                s_stack[sp << bshift] = make_float2(swap ? tl : tr, __int_as_float(swap ? left : right));
                 ++sp;
                 left = __float_as_int(swap ? h0.w : l0.w);
                 right = __float_as_int(swap ? h1.w : l1.w);
@@ -597,7 +597,7 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v)
 // PATH = Params::enablePathTracing.  STATS adds the V/T/h counters used for the roofline's algorithmic bytes.
 // =====================================================================================================================
 template <bool PATH, bool STATS>
-__global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
+__global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
@@ -610,6 +610,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p, co
     float4* s_end = STATS ? s_prims + 6 * p.n_prims : s_mat_w + 3 * p.n_prims;
     float2* s_stack_base = reinterpret_cast<float2*>(s_end);
     const int stack_depth = STATS ? kStackDepth : p.stack_depth;
+    const int kBlock = (int)blockDim.x;           // 256, 512 or 1024
+    const int bshift = 31 - __clz(kBlock);        // per-lane stack entry e lives at [e << bshift]
     LightRec* s_lights = reinterpret_cast<LightRec*>(s_stack_base + stack_depth * kBlock);
     const float4* s_mat = s_mat_w;
 
@@ -707,8 +709,8 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const LaunchParams p, co
                 Hit h;
                 c_rays += 1;
                 bool hit;
-                if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, p.n_small, p.n_prims, ro, rd, tmin, tmax, h);
+                if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
+                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h);
                 if (STATS && hit) c_hits += 1;
 
                 bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
