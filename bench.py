@@ -115,7 +115,12 @@ def main():
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            try:   # RCCL's internal stream at high priority: its small kernels should not queue behind the megakernel
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                dist.init_process_group("nccl", device_id=dev, pg_options=opts)
+            except Exception:
+                dist.init_process_group("nccl", device_id=dev)
 
     W, H, N = args.width, args.height, args.sample
     path = args.mode == "path"
@@ -143,17 +148,21 @@ def main():
     row_index = bands.full_row_index(H, band_h, world, rows_pad, dev) if (rank == 0 and world > 1) else None
 
     def frame(f, stats=False):
-        return capi.make_frame(W, H, N, f, path, False, None, (band_h, world, rank), stats=stats)
+        # N > 1: leave 8 CUs' worth of workgroup slots free so that RCCL's kernels can run beside the persistent megakernel
+        return capi.make_frame(W, H, N, f, path, False, None, (band_h, world, rank), stats=stats,
+                               reserve_cus=(8 if world > 1 and not stats else 0))
 
-    # N > 1: the 8-bit bands are double-buffered so that the gather of frame f (comm stream -> RCCL) overlaps the
+    # N > 1: the 8-bit bands are triple-buffered so that the gather of frame f (comm stream -> RCCL) overlaps the
     # megakernel of frame f+1 (compute stream).  Every frame is still gathered and de-interleaved on rank 0 inside the
     # timed region; the accumulation buffer is single (frame f+1 reads what frame f wrote, same stream).
-    images = [image, torch.zeros_like(image)] if world > 1 else [image]
-    comm = torch.cuda.Stream(dev) if world > 1 else None
-    gathered = [None, None]   # event: gather that last read images[b] has completed
+    NBUF = 3
+    images = [image] + [torch.zeros_like(image) for _ in range(NBUF - 1)] if world > 1 else [image]
+    comm = torch.cuda.Stream(dev, priority=-1) if world > 1 else None
+    gathered = [None] * NBUF   # event: the gather that last read images[b] has completed
+    gather_ws = (torch.empty((world * rows_pad, W, 4), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None)
 
     def step(f):
-        b = f & 1 if world > 1 else 0
+        b = f % NBUF if world > 1 else 0
         if world > 1 and gathered[b] is not None:
             stream.wait_event(gathered[b])            # WAR: do not overwrite a band buffer a gather is still reading
         ctx.bind_output(accum.data_ptr(), images[b].data_ptr(), rows_pad * W)
@@ -169,7 +178,7 @@ def main():
                     if rank == 0:
                         full_image.copy_(full)
                 else:
-                    bands.gather_bands(images[b], H, band_h, dist, dst=0, out=full_image, row_index=row_index)
+                    bands.gather_bands(images[b], H, band_h, dist, dst=0, out=full_image, row_index=row_index, workspace=gather_ws)
                 ev = torch.cuda.Event()
                 ev.record(comm)
             gathered[b] = ev

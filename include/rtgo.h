@@ -82,6 +82,8 @@ typedef struct rtgo_frame {
     uint32_t band_h;           /* row-band height of the interleave inside the window (0 = 4) */
     uint32_t n_ranks, rank;    /* this context renders window rows r with (r / band_h) % n_ranks == rank; 0/1 = all */
     uint32_t collect_stats;    /* 1: also count LBVH node visits / primitive tests / hits (slower instrumented kernel) */
+    uint32_t reserve_cus;      /* leave this many CUs' worth of workgroup slots to other streams (the multi-GPU driver's RCCL
+                                  gather overlaps the next frame's kernel; persistent workgroups would otherwise hold every CU) */
 } rtgo_frame;
 
 typedef struct rtgo_stats {

@@ -19,20 +19,23 @@ def max_local_rows(h, band_h, n_ranks):
     return max(len(band_rows(h, band_h, n_ranks, g)) for g in range(n_ranks))
 
 
-def gather_bands(local, h, band_h, dist, dst=0, group=None, out=None, row_index=None):
+def gather_bands(local, h, band_h, dist, dst=0, group=None, out=None, row_index=None, workspace=None):
     """Gather every rank's compact band tensor [rows_g, w, c] to `dst` and de-interleave into [h, w, c].
 
     `local` must be padded to max_local_rows (equal shapes on every rank).  Returns the full tensor on dst, None elsewhere.
-    `row_index` (optional, precomputed with full_row_index) avoids rebuilding the permutation every frame."""
+    `row_index` (precomputed with full_row_index) and `workspace` (a [world * rows_pad, w, c] tensor on dst) let a per-frame
+    caller avoid rebuilding the permutation and re-allocating the receive buffers."""
     import torch
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if world == 1:
         return local[:h]
     if rank == dst:
-        parts = [torch.empty_like(local) for _ in range(world)]
+        rows_pad = local.shape[0]
+        stacked = workspace if workspace is not None else torch.empty((world * rows_pad,) + tuple(local.shape[1:]),
+                                                                      dtype=local.dtype, device=local.device)
+        parts = [stacked[g * rows_pad:(g + 1) * rows_pad] for g in range(world)]   # views: the receives land in place
         dist.gather(local, parts, dst=dst, group=group)
-        stacked = torch.cat(parts, dim=0)
         if row_index is None:
             row_index = full_row_index(h, band_h, world, local.shape[0], local.device)
         if out is None:

@@ -49,7 +49,7 @@ class Frame(C.Structure):
                 ("max_trace_depth", C.c_int32), ("frame_count", C.c_uint32), ("path_tracing", C.c_uint32),
                 ("use_ambient", C.c_uint32), ("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32),
                 ("h", C.c_uint32), ("band_h", C.c_uint32), ("n_ranks", C.c_uint32), ("rank", C.c_uint32),
-                ("collect_stats", C.c_uint32)]
+                ("collect_stats", C.c_uint32), ("reserve_cus", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -237,8 +237,8 @@ class Context:
 
 
 def make_frame(width, height, sqrt_spp=1, frame_count=0, path=True, ambient=False, window=None, bands=(4, 1, 0),
-               max_depth=5, stats=False):
+               max_depth=5, stats=False, reserve_cus=0):
     x0, y0, w, h = window if window is not None else (0, 0, width, height)
     band_h, n_ranks, rank = bands
     return Frame(width, height, sqrt_spp, max_depth, frame_count, int(path), int(ambient), x0, y0, w, h, band_h,
-                 n_ranks, rank, int(stats))
+                 n_ranks, rank, int(stats), int(reserve_cus))

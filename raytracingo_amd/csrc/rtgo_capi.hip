@@ -384,7 +384,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         }
     }
     if (best_waves == 0) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
-    unsigned int grid = (unsigned int)(c->num_cus * blocks_per_cu);
+    int cus = c->num_cus - (int)(f->reserve_cus < (uint32_t)c->num_cus / 2 ? f->reserve_cus : (uint32_t)c->num_cus / 2);
+    unsigned int grid = (unsigned int)(cus * blocks_per_cu);
     const unsigned int need = (p.n_tiles + (block / 64) - 1) / (block / 64);
     if (grid > need) grid = need;
 

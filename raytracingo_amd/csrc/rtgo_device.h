@@ -571,10 +571,9 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
             theta = glossy_theta(base, expo);
         }
         float st, ct, sp, cp;
-        st = sinf(theta);
-        ct = cosf(theta);
-        sp = sinf(phi);
-        cp = cosf(phi);
+        // sincosf shares the range reduction and returns bit for bit what sinf and cosf return (tools/sincos_probe.hip)
+        sincosf(theta, &st, &ct);
+        sincosf(phi, &sp, &cp);
         ray = vsub(vadd(vscale(X, st * cp), vscale(Y, ct)), vscale(Z, st * sp));
     } while (vdot(normal, ray) < 0.f);
     return ray;
