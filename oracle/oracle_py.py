@@ -179,3 +179,44 @@ def lbvh(aabb):
         arr[i, 3:6] = list(nodes[i].bmax)
         links[i] = (nodes[i].left, nodes[i].right)
     return arr[:, :6], links, code, order
+
+
+def scene_from_tables(types, M, mat, lights16, cam12, bg=(0.0, 0.0, 0.0), aabb=None):
+    """build an oracle Scene from flattened tables (the same arrays the C ABI takes); AABBs default to the CubeBox rule"""
+    sc = Scene()
+    n = len(types)
+    assert n <= MAX_PRIMS
+    sc.n_prims = n
+    M = f32(M).reshape(n, 16)
+    mat = f32(mat).reshape(n, 10)
+    for i in range(n):
+        p = sc.prims[i]
+        p.type = int(types[i])
+        p.M[:] = M[i].tolist()
+        p.kd[:] = mat[i, 0:3].tolist()
+        p.kr[:] = mat[i, 3:6].tolist()
+        p.specularity = float(mat[i, 6])
+        p.Le[:] = mat[i, 7:10].tolist()
+        if aabb is None:
+            bb = np.zeros(6, dtype=np.float32)
+            lib().oracle_prim_aabb(fptr(M[i].copy()), fptr(bb))
+        else:
+            bb = f32(aabb[i])
+        sc.aabb[i][:] = bb.tolist()
+    lights16 = f32(lights16).reshape(-1, 16)
+    sc.n_lights = lights16.shape[0]
+    for i in range(sc.n_lights):
+        r = lights16[i].tolist()
+        L = sc.lights[i]
+        L.corner[:], L.v1[:], L.v2[:], L.normal[:], L.color[:], L.falloff = r[0:3], r[3:6], r[6:9], r[9:12], r[12:15], r[15]
+    cam12 = f32(cam12)
+    sc.eye[:], sc.U[:], sc.V[:], sc.W[:] = cam12[0:3].tolist(), cam12[3:6].tolist(), cam12[6:9].tolist(), cam12[9:12].tolist()
+    sc.bg[:] = list(bg)
+    return sc
+
+
+def light_from_matrix(M, color=(1.0, 1.0, 1.0), falloff=0.0):
+    """SurfaceLight record (16 floats) of a unit rectangle under M (light.cpp:9-28)"""
+    L = Light()
+    lib().oracle_light_from_matrix(fptr(f32(M).reshape(16).copy()), fptr(f32(color)), float(falloff), C.byref(L))
+    return np.array(list(L.corner) + list(L.v1) + list(L.v2) + list(L.normal) + list(L.color) + [L.falloff], dtype=np.float32)

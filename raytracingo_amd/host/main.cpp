@@ -22,6 +22,7 @@ static void printUsageAndExit(const char* argv0)
               << "         --useAmbient                Use an ambient coefficient instead of diffuse inter-reflection\n"
               << "         --frames=<K>                Progressive frames to accumulate; default 1   [headless addition]\n"
               << "         --out=<file.ppm>            Write the final 8-bit image (P6)              [headless addition]\n"
+              << "         --out-accum=<file.pfm>      Write the float accumulation buffer (PFM)       [headless addition]\n"
               << "         --device=<i>                GPU index; default 0                          [headless addition]\n";
     std::exit(1);
 }
@@ -44,7 +45,7 @@ int main(int argc, char* argv[])
     bool modeFound = false, sceneFound = false, useAmbient = false;
     RenderMode mode = RenderMode::PATH_TRACING;
     SceneModel scene = SceneModel::CORNELL;
-    std::string out;
+    std::string out, outAccum;
     static const struct { const char* name; SceneModel model; } kScenes[] = {
         {"plateau", SceneModel::PLATE}, {"cornell", SceneModel::CORNELL}, {"slide", SceneModel::SLIDE}, {"window", SceneModel::WINDOW},
         {"balls", SceneModel::BALLS}, {"checkered", SceneModel::CHECKERED}, {"mirror_spheres", SceneModel::MIRROR_SPHERES},
@@ -70,6 +71,7 @@ int main(int argc, char* argv[])
             } else if (is("--sample=")) sample = std::atoi(value("--sample=").c_str());
             else if (is("--useAmbient")) useAmbient = true;
             else if (is("--frames=")) frames = std::atoi(value("--frames=").c_str());
+            else if (is("--out-accum=")) outAccum = value("--out-accum=");
             else if (is("--out=")) out = value("--out=");
             else if (is("--device=")) device = std::atoi(value("--device=").c_str());
             else { std::cerr << "Unknown option '" << arg << "'\n"; printUsageAndExit(argv[0]); }
@@ -82,6 +84,7 @@ int main(int argc, char* argv[])
         renderer.SetDevice(device);
         renderer.SetFrames(frames);
         renderer.SetOutputFile(out);
+        renderer.SetAccumFile(outAccum);
         renderer.Display();
         const rtgo_stats st = renderer.Stats();
         std::cout << "frames " << st.launches << ", rays " << st.rays_total << ", kernel ms " << st.total_launch_ms << ", Mray/s "

@@ -136,6 +136,10 @@ void Renderer::Display()
         SavePPM(m_outputFile, img.data(), m_scene->GetCameraWidth(), m_scene->GetCameraHeight());
         std::cout << "Save complete" << std::endl;
     }
+    if (!m_accumFile.empty()) {
+        const std::vector<float> acc = ReadAccum();
+        SavePFM(m_accumFile, acc.data(), m_scene->GetCameraWidth(), m_scene->GetCameraHeight());
+    }
 }
 
 std::vector<unsigned char> Renderer::ReadImage()
@@ -174,6 +178,24 @@ void Renderer::SavePPM(const std::string& path, const unsigned char* rgba, unsig
             row[3 * x + 2] = src[4 * x + 2];
         }
         out.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size()));
+    }
+}
+
+void Renderer::SavePFM(const std::string& path, const float* rgba, unsigned int width, unsigned int height)
+{
+    if (!rgba || width < 1 || height < 1) throw std::invalid_argument("Image is ill-formed. Not saving");
+    std::ofstream out(path, std::ios::out | std::ios::binary);
+    if (!out.is_open()) throw std::runtime_error("Could not open file for SavePFM");
+    out << "PF\n" << width << " " << height << "\n-1.0\n";  // negative scale = little endian; rows go bottom to top
+    std::vector<float> row(static_cast<size_t>(width) * 3);
+    for (unsigned int y = 0; y < height; ++y) {
+        const float* src = rgba + static_cast<size_t>(y) * width * 4;
+        for (unsigned int x = 0; x < width; ++x) {
+            row[3 * x + 0] = src[4 * x + 0];
+            row[3 * x + 1] = src[4 * x + 1];
+            row[3 * x + 2] = src[4 * x + 2];
+        }
+        out.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(float)));
     }
 }
 

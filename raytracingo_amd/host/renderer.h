@@ -27,6 +27,8 @@ public:
     // ---- headless controls (no reference counterpart: the reference is interactive only) ----
     void SetFrames(int frames) { m_frames = frames; }
     void SetOutputFile(const std::string& path) { m_outputFile = path; }
+    /// also dump the float accumulation buffer (PFM, RGB float32, bottom row first as PFM specifies = buffer order)
+    void SetAccumFile(const std::string& path) { m_accumFile = path; }
     void SetDevice(int device) { m_device = device; }
     /// render exactly one more frame (frameCount advances like Renderer::Update does)
     void RenderFrame();
@@ -36,6 +38,8 @@ public:
     rtgo_stats Stats();
     /// P6 file, rows flipped so that the top row comes first, alpha dropped (sutil.cpp:81-101, 377-388)
     static void SavePPM(const std::string& path, const unsigned char* rgba, unsigned int width, unsigned int height);
+    /// "PF" file, little-endian float RGB; the reference never saves its accumulation buffer, this does
+    static void SavePFM(const std::string& path, const float* rgba, unsigned int width, unsigned int height);
 
 private:
     std::shared_ptr<Scene> m_scene;
@@ -48,6 +52,7 @@ private:
     int m_frames;
     int m_device;
     std::string m_outputFile;
+    std::string m_accumFile;
 
     void Initialize();
     void CreateContext();

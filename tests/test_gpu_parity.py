@@ -244,3 +244,106 @@ def test_golden_oracle_renders(capi, oracle):
             acc, img = gpu_render(capi, ctx, m["W"], m["H"], m["N"], fr, m["path"], m["ambient"])
         assert_parity(acc, z["accum_%d" % i], img, z["image_%d" % i], min_frac=0.985, what=str(m))
         ctx.close()
+
+
+def _random_scene(oracle, seed, W, H):
+    """a random scene through the plugin surface: all four primitive types under random translate*rotate*scale (non-uniform),
+    diffuse / glossy / mirror / emissive materials, one to three rectangular lights, a non-black background"""
+    rng = np.random.RandomState(seed)
+    L = oracle.lib()
+
+    def trs():
+        T, R, S, TR, out = [np.zeros(16, dtype=np.float32) for _ in range(5)]
+        L.oracle_mat_translate(*[np.float32(v) for v in rng.uniform(-3.5, 3.5, 3)], oracle.fptr(T))
+        ax = rng.uniform(-1, 1, 3)
+        ax = ax / np.linalg.norm(ax)
+        L.oracle_mat_rotate(np.float32(rng.uniform(-3.1, 3.1)), *[np.float32(v) for v in ax], oracle.fptr(R))
+        L.oracle_mat_scale(*[np.float32(v) for v in rng.uniform(0.3, 2.2, 3)], oracle.fptr(S))
+        L.oracle_mat_mul(oracle.fptr(T), oracle.fptr(R), oracle.fptr(TR))
+        L.oracle_mat_mul(oracle.fptr(TR), oracle.fptr(S), oracle.fptr(out))
+        return out
+
+    n = int(rng.randint(12, 70))
+    types = rng.randint(0, 4, n)
+    M = np.stack([trs() for _ in range(n)])
+    mat = np.zeros((n, 10), dtype=np.float32)
+    mat[:, 0:3] = rng.uniform(0.1, 1.0, (n, 3))
+    mat[:, 3:6] = rng.uniform(0.0, 0.8, (n, 1))
+    mat[:, 6] = rng.choice([0.0, 1.0, 100.0, 10000.0], n)
+    # a big floor and a big emissive ceiling light so that most paths end somewhere
+    floor, ceil = np.zeros(16, dtype=np.float32), np.zeros(16, dtype=np.float32)
+    S = np.zeros(16, dtype=np.float32)
+    T = np.zeros(16, dtype=np.float32)
+    R = np.zeros(16, dtype=np.float32)
+    L.oracle_mat_translate(0.0, -4.0, 0.0, oracle.fptr(T))
+    L.oracle_mat_scale(14.0, 1.0, 14.0, oracle.fptr(S))
+    L.oracle_mat_mul(oracle.fptr(T), oracle.fptr(S), oracle.fptr(floor))
+    L.oracle_mat_translate(0.0, 4.5, 0.0, oracle.fptr(T))
+    L.oracle_mat_rotate(np.float32(np.pi), 1.0, 0.0, 0.0, oracle.fptr(R))
+    TR = np.zeros(16, dtype=np.float32)
+    L.oracle_mat_mul(oracle.fptr(T), oracle.fptr(R), oracle.fptr(TR))
+    L.oracle_mat_scale(6.0, 1.0, 6.0, oracle.fptr(S))
+    L.oracle_mat_mul(oracle.fptr(TR), oracle.fptr(S), oracle.fptr(ceil))
+    types[0], M[0], mat[0] = 2, floor, [0.7, 0.7, 0.7, 0.3, 0.3, 0.3, 1.0, 0, 0, 0]
+    types[1], M[1], mat[1] = 2, ceil, [0, 0, 0, 0, 0, 0, 1.0, 12.0, 12.0, 12.0]
+    lights = [oracle.light_from_matrix(ceil, falloff=0.02)]
+    for k in range(int(rng.randint(0, 3))):
+        idx = 2 + k
+        types[idx] = 2
+        mat[idx] = [0, 0, 0, 0, 0, 0, 1.0, 9.0, 9.0, 9.0]
+        lights.append(oracle.light_from_matrix(M[idx], falloff=float(rng.uniform(0, 0.1))))
+    cam = oracle.scene_tables(oracle.scene("cornell", W, H))["cam"]
+    bg = (0.05, 0.07, 0.1)
+    sc = oracle.scene_from_tables(types, M, mat, np.stack(lights), cam, bg)
+    return sc, oracle.scene_tables(sc)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_scenes_through_the_plugin_surface(capi, oracle, seed):
+    W, H, n = 80, 60, 2
+    sc, t = _random_scene(oracle, seed, W, H)
+    ctx = capi.Context(0)
+    ctx.set_scene(t["type"], t["M"], t["mat"], None)   # AABBs derived on the device (CubeBox rule)
+    ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
+    ctx.set_background(t["bg"])
+    ctx.set_lights(t["lights"])
+    boxes, links, inv, aabb = ctx.read_bvh()
+    assert np.array_equal(aabb.view(np.uint32), t["aabb"].view(np.uint32))
+    for path, amb in ((True, False), (False, False), (False, True)):
+        ctx.reset_stats()
+        acc, img = gpu_render(capi, ctx, W, H, n, 0, path, amb, stats=True)
+        racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, ambient=amb, mode=1))
+        r0, _, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, ambient=amb, mode=0))
+        assert np.array_equal(r0.view(np.uint32), racc.view(np.uint32)), "oracle literal != oracle LBVH"
+        assert_parity(acc, racc, img, rimg, min_frac=0.98, what="random scene %d %s" % (seed, (path, amb)))
+        fast, fimg = gpu_render(capi, ctx, W, H, n, 0, path, amb, stats=False)
+        assert np.array_equal(fast.view(np.uint32), acc.view(np.uint32)), "fast walk != canonical walk"
+    ctx.close()
+
+
+def test_cli_headless_ppm_and_pfm(tmp_path, capi, oracle):
+    """the `engine` command line (engine/main.cpp flags + --frames/--out/--out-accum) end to end: P6 file with rows flipped and
+    alpha dropped (sutil.cpp:81-101, 377-388), PFM of the accumulation buffer"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "raytracingo_amd", "rtgo_engine")
+    W, H = 80, 48
+    ppm, pfm = str(tmp_path / "o.ppm"), str(tmp_path / "o.pfm")
+    r = subprocess.run([exe, "--scene=mirror_spheres", "--mode=path", "--dim=%dx%d" % (W, H), "--sample=2", "--frames=2",
+                        "--out=" + ppm, "--out-accum=" + pfm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    sc = oracle.scene("mirror_spheres", W, H)
+    racc = None
+    for f in range(2):
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, 2, f, path=True, mode=1), accum_prev=racc)
+    raw = open(ppm, "rb").read()
+    head = b"P6\n%d %d\n255\n" % (W, H)
+    assert raw.startswith(head) and len(raw) == len(head) + W * H * 3
+    img = np.frombuffer(raw[len(head):], dtype=np.uint8).reshape(H, W, 3)[::-1]     # file is top row first
+    rawf = open(pfm, "rb").read()
+    headf = b"PF\n%d %d\n-1.0\n" % (W, H)
+    assert rawf.startswith(headf)
+    acc = np.frombuffer(rawf[len(headf):], dtype="<f4").reshape(H, W, 3)
+    acc4 = np.concatenate([acc, np.ones((H, W, 1), np.float32)], axis=2)
+    img4 = np.concatenate([img, np.full((H, W, 1), 255, np.uint8)], axis=2)
+    assert_parity(acc4, racc, img4, rimg, what="CLI")
