@@ -96,6 +96,8 @@ typedef struct rtgo_stats {
     float total_launch_ms;    /* sum over launches since rtgo_reset_stats */
     uint32_t launches;
     uint32_t lbvh_depth;      /* depth of the on-device LBVH */
+    uint64_t dbg_fast_boxes;  /* diagnostic builds (-DRTGO_FAST_COUNTERS) only: boxes tested by the fast walk, else 0 */
+    uint64_t dbg_fast_tests;  /* diagnostic builds only: leaf tests of the fast walk incl. the up-front list, else 0 */
 } rtgo_stats;
 
 typedef struct rtgo_ctx rtgo_ctx;

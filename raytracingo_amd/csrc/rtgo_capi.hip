@@ -461,6 +461,8 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     out->total_launch_ms = c->total_ms;
     out->launches = c->launches;
     out->lbvh_depth = (uint32_t)c->lbvh_depth;
+    out->dbg_fast_boxes = h[5];
+    out->dbg_fast_tests = h[6];
     return RTGO_OK;
 }
 

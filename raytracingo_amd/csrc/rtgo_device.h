@@ -461,7 +461,8 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
                                                  const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int bshift,
-                                                 int n_small, int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out)
+                                                 int n_small, int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out,
+                                                 unsigned int& dbg_boxes, unsigned int& dbg_tests)
 {
     FastHit best;
     best.t = tmax;
@@ -477,6 +478,9 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     // It also gives every ray a closest-hit bound before it enters the tree.
 #pragma unroll 4
     for (int k = n_small; k < n_prims; ++k) leaf_test(g_fprims, k, o, d, tmin, best);
+#ifdef RTGO_FAST_COUNTERS
+    dbg_tests += (unsigned int)(n_prims - n_small);
+#endif
     const v3 id = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
     float tn;
@@ -507,6 +511,9 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
             const float4 l0 = s_fnodes[2 * left], l1 = s_fnodes[2 * left + 1];
             const float4 h0 = s_fnodes[2 * right], h1 = s_fnodes[2 * right + 1];
             float tl, tr;
+#ifdef RTGO_FAST_COUNTERS
+            dbg_boxes += 2;
+#endif
             const bool hl = box_fast(l0, l1, id, noid, tmin, best.t, tl);
             const bool hr = box_fast(h0, h1, id, noid, tmin, best.t, tr);
             if (hl && hr) {
@@ -527,6 +534,9 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
         }
         if (have) {
             const int first = left, cnt = -right;
+#ifdef RTGO_FAST_COUNTERS
+            dbg_tests += (unsigned int)cnt;
+#endif
             for (int k = 0; k < cnt; ++k) leaf_test(s_fprims, first + k, o, d, tmin, best);
             have = pop();
         }
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
                 c_rays += 1;
                 bool hit;
                 if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h);
+                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h, c_nodes, c_tests);
                 if (STATS && hit) c_hits += 1;
 
                 bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
@@ -886,6 +896,17 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
         c_tests = wave_sum(c_tests);
         c_hits = wave_sum(c_hits);
     }
+#ifdef RTGO_FAST_COUNTERS
+    // diagnostic build only: what the FAST walk itself visits (boxes tested, leaf tests incl. the up-front list)
+    if (!STATS) {
+        c_nodes = wave_sum(c_nodes);
+        c_tests = wave_sum(c_tests);
+        if (lane == 0) {
+            atomicAdd(&p.counters[5], (unsigned long long)c_nodes);
+            atomicAdd(&p.counters[6], (unsigned long long)c_tests);
+        }
+    }
+#endif
     if (lane == 0) {
         atomicAdd(&p.counters[0], (unsigned long long)c_rays);
         if (!PATH) atomicAdd(&p.counters[1], (unsigned long long)c_occl);
