@@ -36,6 +36,17 @@ int rtgo_host_scene_build(const char* scene_name, uint32_t width, uint32_t heigh
 int rtgo_host_render(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient,
                      int frames, int device, void* host_image, void* host_accum, rtgo_stats* stats);
 
+/* A scripted interactive session with engine::host::Renderer: what the GLFW callbacks + frame loop of the reference do
+   (renderer.cpp:36-145, 679-747, 841-862), without a window.  All return 0 or an RTGO_E_* code. */
+typedef struct rtgo_host_session rtgo_host_session;
+int rtgo_host_session_open(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient,
+                           int device, rtgo_host_session** out);
+int rtgo_host_session_frame(rtgo_host_session* s);                                   /* Update + LaunchFrame */
+int rtgo_host_session_move_camera(rtgo_host_session* s, const float eye[3], const float lookat[3], const float up[3]);
+int rtgo_host_session_resize(rtgo_host_session* s, uint32_t width, uint32_t height);
+int rtgo_host_session_read(rtgo_host_session* s, void* host_image, void* host_accum, uint32_t* frame_count);
+int rtgo_host_session_close(rtgo_host_session* s);
+
 const char* rtgo_host_last_error(void);
 
 #ifdef __cplusplus

@@ -111,4 +111,82 @@ int rtgo_host_render(const char* scene_name, const char* mode, uint32_t width, u
     return RTGO_OK;
 }
 
+struct rtgo_host_session {
+    std::shared_ptr<Scene> scene;
+    std::unique_ptr<Renderer> renderer;
+};
+
+#define RTGO_SESSION_TRY(body)              \
+    try {                                   \
+        body;                               \
+    } catch (const std::exception& e) {     \
+        g_error = e.what();                 \
+        return RTGO_E_STATE;                \
+    }                                       \
+    return RTGO_OK;
+
+int rtgo_host_session_open(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient, int device,
+                           rtgo_host_session** out)
+{
+    SceneModel model;
+    if (!out || !scene_name || !mode || !scene_from_name(scene_name, model) || width == 0 || height == 0 || sample < 1) {
+        g_error = "rtgo_host_session_open: bad argument";
+        return RTGO_E_INVALID;
+    }
+    const std::string m(mode);
+    if (m != "path" && m != "distributed") {
+        g_error = "rtgo_host_session_open: mode must be path or distributed";
+        return RTGO_E_INVALID;
+    }
+    *out = nullptr;
+    RTGO_SESSION_TRY({
+        auto* s = new rtgo_host_session();
+        s->scene = std::make_shared<Scene>(model, width, height);
+        s->renderer.reset(new Renderer(s->scene, m == "path" ? RenderMode::PATH_TRACING : RenderMode::DISTRIBUTED_RAY_TRACING, sample, ambient != 0));
+        s->renderer->SetDevice(device);
+        *out = s;
+    })
+}
+
+int rtgo_host_session_frame(rtgo_host_session* s)
+{
+    if (!s) return RTGO_E_INVALID;
+    RTGO_SESSION_TRY(s->renderer->RenderFrame())
+}
+
+int rtgo_host_session_move_camera(rtgo_host_session* s, const float eye[3], const float lookat[3], const float up[3])
+{
+    if (!s || !eye || !lookat || !up) return RTGO_E_INVALID;
+    RTGO_SESSION_TRY(s->renderer->MoveCamera(make_float3(eye[0], eye[1], eye[2]), make_float3(lookat[0], lookat[1], lookat[2]),
+                                             make_float3(up[0], up[1], up[2])))
+}
+
+int rtgo_host_session_resize(rtgo_host_session* s, uint32_t width, uint32_t height)
+{
+    if (!s) return RTGO_E_INVALID;
+    RTGO_SESSION_TRY(s->renderer->Resize(width, height))
+}
+
+int rtgo_host_session_read(rtgo_host_session* s, void* host_image, void* host_accum, uint32_t* frame_count)
+{
+    if (!s) return RTGO_E_INVALID;
+    RTGO_SESSION_TRY({
+        if (host_image) {
+            const std::vector<unsigned char> img = s->renderer->ReadImage();
+            std::memcpy(host_image, img.data(), img.size());
+        }
+        if (host_accum) {
+            const std::vector<float> acc = s->renderer->ReadAccum();
+            std::memcpy(host_accum, acc.data(), acc.size() * sizeof(float));
+        }
+        if (frame_count) *frame_count = s->renderer->FrameCount();
+    })
+}
+
+int rtgo_host_session_close(rtgo_host_session* s)
+{
+    delete s;
+    return RTGO_OK;
+}
+
 }  // extern "C"

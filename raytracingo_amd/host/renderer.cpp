@@ -10,7 +10,8 @@ namespace host {
 
 Renderer::Renderer(std::shared_ptr<Scene> scene, RenderMode renderMode, int sqrtSamplePerPixel, bool useAmbientCoeff)
     : m_scene(scene), m_renderMode(renderMode), m_useAmbientCoefficient(useAmbientCoeff), m_sqrtSamplePerPixel(sqrtSamplePerPixel),
-      m_context(nullptr), m_params(), m_firstLaunch(true), m_frames(1), m_device(0)
+      m_context(nullptr), m_params(), m_firstLaunch(true), m_cameraChangedFlag(false), m_windowResizeFlag(false), m_frames(1),
+      m_device(0)
 {
 }
 
@@ -107,9 +108,49 @@ void Renderer::WriteLights()
 
 void Renderer::Update()
 {
-    // frame counter rule of renderer.cpp:682 (no camera motion or resize can happen headlessly)
-    m_params.frame_count = m_firstLaunch ? 0 : m_params.frame_count + 1;
+    // frame counter rule of renderer.cpp:682: any camera change or resize restarts the running average
+    m_params.frame_count = (m_cameraChangedFlag || m_windowResizeFlag || m_firstLaunch) ? 0 : m_params.frame_count + 1;
     m_firstLaunch = false;
+    UpdateCamera();
+    ResizeBuffers();
+}
+
+void Renderer::UpdateCamera()
+{
+    // renderer.cpp:703-717: aspect ratio from the current image size, then the raygen record is re-uploaded
+    if (!m_cameraChangedFlag) return;
+    m_cameraChangedFlag = false;
+    m_scene->GetCamera()->setAspectRatio(static_cast<float>(m_params.image_width) / static_cast<float>(m_params.image_height));
+    CreateRayGen();
+}
+
+void Renderer::ResizeBuffers()
+{
+    // renderer.cpp:733-747: output buffer and accumulation buffer are re-allocated for the new size
+    if (!m_windowResizeFlag) return;
+    m_windowResizeFlag = false;
+    Check(rtgo_resize(m_context, static_cast<size_t>(m_params.image_width) * m_params.image_height), "rtgo_resize");
+}
+
+void Renderer::MoveCamera(const float3& eye, const float3& lookat, const float3& up)
+{
+    if (!m_context) Initialize();
+    const std::shared_ptr<sutil::Camera> camera = m_scene->GetCamera();
+    camera->setEye(eye);
+    camera->setLookat(lookat);
+    camera->setUp(up);
+    m_cameraChangedFlag = true;
+}
+
+void Renderer::Resize(unsigned int width, unsigned int height)
+{
+    if (!m_context) Initialize();
+    if (width < 1 || height < 1) throw std::invalid_argument("Renderer::Resize: empty image");
+    // windowSizeCallback (renderer.cpp:61-78) flags both: the aspect ratio feeds the camera frame
+    m_params.image_width = width;
+    m_params.image_height = height;
+    m_cameraChangedFlag = true;
+    m_windowResizeFlag = true;
 }
 
 void Renderer::LaunchFrame()

@@ -32,6 +32,14 @@ public:
     void SetDevice(int device) { m_device = device; }
     /// render exactly one more frame (frameCount advances like Renderer::Update does)
     void RenderFrame();
+    /// what the trackball callbacks do to the camera (renderer.cpp:36-145 set cameraChangedFlag): the next frame restarts the
+    /// accumulation at frameCount 0 and re-uploads the raygen record (Renderer::UpdateCamera, renderer.cpp:703-717)
+    void MoveCamera(const float3& eye, const float3& lookat, const float3& up);
+    /// what windowSizeCallback does (renderer.cpp:61-78 set windowResizeFlag): new image size, aspect ratio, buffers; restarts at 0
+    void Resize(unsigned int width, unsigned int height);
+    unsigned int Width() const { return m_params.image_width; }
+    unsigned int Height() const { return m_params.image_height; }
+    unsigned int FrameCount() const { return m_params.frame_count; }
     /// the 8-bit image (uchar4, row 0 = bottom row) and the float accumulation buffer of the last frame
     std::vector<unsigned char> ReadImage();
     std::vector<float> ReadAccum();
@@ -49,6 +57,8 @@ private:
     rtgo_ctx* m_context;
     rtgo_frame m_params;   // the launch constants the reference keeps in device::Params
     bool m_firstLaunch;
+    bool m_cameraChangedFlag;   // RendererState::cameraChangedFlag
+    bool m_windowResizeFlag;    // RendererState::windowResizeFlag
     int m_frames;
     int m_device;
     std::string m_outputFile;
@@ -61,6 +71,8 @@ private:
     void CreateShapes();
     void WriteLights();
     void Update();
+    void UpdateCamera();
+    void ResizeBuffers();
     void LaunchFrame();
     void CleanUp();
     void Check(int rc, const char* what) const;

@@ -76,3 +76,48 @@ def host_render(name, mode, width, height, sample=1, ambient=False, frames=1, de
     if rc != 0:
         raise capi.RtgoError("rtgo_host_render failed (%d): %s" % (rc, load().rtgo_host_last_error().decode()))
     return acc, img, st.as_dict()
+
+
+class Session:
+    """scripted interactive session with the C++ Renderer (rtgo_host_session_*): frames, camera moves, resizes"""
+
+    def __init__(self, name, mode, width, height, sample=1, ambient=False, device=0):
+        L = load()
+        L.rtgo_host_session_open.restype = C.c_int
+        L.rtgo_host_session_open.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.rtgo_host_session_frame.argtypes = [C.c_void_p]
+        L.rtgo_host_session_move_camera.argtypes = [C.c_void_p] + [C.POINTER(C.c_float)] * 3
+        L.rtgo_host_session_resize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.rtgo_host_session_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
+        L.rtgo_host_session_close.argtypes = [C.c_void_p]
+        self._L = L
+        self._h = C.c_void_p()
+        self.width, self.height = width, height
+        self._ok(L.rtgo_host_session_open(name.encode(), mode.encode(), width, height, sample, int(ambient), device, C.byref(self._h)))
+
+    def _ok(self, rc):
+        if rc != 0:
+            raise capi.RtgoError("host session call failed (%d): %s" % (rc, self._L.rtgo_host_last_error().decode()))
+
+    def frame(self):
+        self._ok(self._L.rtgo_host_session_frame(self._h))
+
+    def move_camera(self, eye, lookat, up):
+        a = [np.ascontiguousarray(v, dtype=np.float32) for v in (eye, lookat, up)]
+        self._ok(self._L.rtgo_host_session_move_camera(self._h, *[x.ctypes.data_as(C.POINTER(C.c_float)) for x in a]))
+
+    def resize(self, width, height):
+        self._ok(self._L.rtgo_host_session_resize(self._h, width, height))
+        self.width, self.height = width, height
+
+    def read(self):
+        acc = np.empty((self.height, self.width, 4), dtype=np.float32)
+        img = np.empty((self.height, self.width, 4), dtype=np.uint8)
+        fc = C.c_uint32(0)
+        self._ok(self._L.rtgo_host_session_read(self._h, img.ctypes.data, acc.ctypes.data, C.byref(fc)))
+        return acc, img, int(fc.value)
+
+    def close(self):
+        if self._h:
+            self._L.rtgo_host_session_close(self._h)
+            self._h = None

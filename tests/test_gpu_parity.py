@@ -347,3 +347,47 @@ def test_cli_headless_ppm_and_pfm(tmp_path, capi, oracle):
     acc4 = np.concatenate([acc, np.ones((H, W, 1), np.float32)], axis=2)
     img4 = np.concatenate([img, np.full((H, W, 1), 255, np.uint8)], axis=2)
     assert_parity(acc4, racc, img4, rimg, what="CLI")
+
+
+def test_interactive_session_camera_and_resize(capi, oracle):
+    """the caller side of the boundary without a window: a camera move or a resize restarts the running
+    average at frameCount 0 (renderer.cpp:682) with the new raygen record / buffers (renderer.cpp:703-747)"""
+    from raytracingo_amd import scene as hscene
+    import ctypes as C
+    W, H = 96, 64
+    s = hscene.Session("cornell", "path", W, H, sample=2)
+    for _ in range(3):
+        s.frame()
+    acc, img, fc = s.read()
+    assert fc == 2
+    sc = oracle.scene("cornell", W, H)
+    racc = None
+    for f in range(3):
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, 2, f, path=True, mode=1), accum_prev=racc)
+    assert_parity(acc, racc, img, rimg, what="session frames 0-2")
+    # move the camera: next frame is frame 0 of the new view
+    eye, look, up = [3.0, 1.0, 12.0], [0.0, -0.5, 0.0], [0.0, 1.0, 0.0]
+    s.move_camera(eye, look, up)
+    s.frame()
+    acc, img, fc = s.read()
+    assert fc == 0
+    U, V, Wv = [np.zeros(3, dtype=np.float32) for _ in range(3)]
+    oracle.lib().oracle_camera_uvw(oracle.fptr(oracle.f32(eye)), oracle.fptr(oracle.f32(look)), oracle.fptr(oracle.f32(up)), 60.0,
+                                   np.float32(np.float32(W) / np.float32(H)), oracle.fptr(U), oracle.fptr(V), oracle.fptr(Wv))
+    sc.eye[:], sc.U[:], sc.V[:], sc.W[:] = eye, U.tolist(), V.tolist(), Wv.tolist()
+    racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, 2, 0, path=True, mode=1))
+    assert_parity(acc, racc, img, rimg, what="after camera move")
+    s.frame()
+    assert s.read()[2] == 1
+    # resize: new buffers, new aspect ratio, frame 0 again
+    W2, H2 = 128, 48
+    s.resize(W2, H2)
+    s.frame()
+    acc, img, fc = s.read()
+    assert fc == 0 and acc.shape == (H2, W2, 4)
+    oracle.lib().oracle_camera_uvw(oracle.fptr(oracle.f32(eye)), oracle.fptr(oracle.f32(look)), oracle.fptr(oracle.f32(up)), 60.0,
+                                   np.float32(np.float32(W2) / np.float32(H2)), oracle.fptr(U), oracle.fptr(V), oracle.fptr(Wv))
+    sc.U[:], sc.V[:], sc.W[:] = U.tolist(), V.tolist(), Wv.tolist()
+    racc, rimg, _ = oracle.render(sc, oracle.frame(W2, H2, 2, 0, path=True, mode=1))
+    assert_parity(acc, racc, img, rimg, what="after resize")
+    s.close()
