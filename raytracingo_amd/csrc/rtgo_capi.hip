@@ -40,6 +40,7 @@ struct rtgo_ctx {
     int lbvh_depth = 0;
     int fast_depth = 0;
     int n_small = 0;
+    float bounds[6] = {0, 0, 0, 0, 0, 0};  // tight world bounds of the scene (min xyz, max xyz)
     int leaf_budget = kDefaultLeafBudget;
     LightRec* d_lights = nullptr;
     int n_lights = 0;
@@ -90,6 +91,58 @@ static int harvest_events(rtgo_ctx* c, int count)
     return RTGO_OK;
 }
 
+// window rows below y that this rank owns under the band interleave
+static uint32_t owned_rows_below(uint32_t y, uint32_t band_h, uint32_t n_ranks, uint32_t rank)
+{
+    if (n_ranks <= 1) return y;
+    const uint32_t full = y / band_h, part = y % band_h;
+    const uint32_t owned_full = full > rank ? (full - rank - 1) / n_ranks + 1 : 0;
+    return owned_full * band_h + ((full % n_ranks == rank) ? part : 0);
+}
+
+// Screen rectangle (in local tile coordinates) that can contain geometry: the 8 corners of the scene's tight bounds through
+// the pinhole camera of the raygen program (d = dx*U + dy*V + W, kernel.cu:214-220).  Conservative: padded by a pixel, and
+// the whole window whenever a corner is not in front of the eye.  Only the ORDER in which tiles are handed out depends on it.
+static void hot_rectangle(const rtgo_ctx* c, LaunchParams& p)
+{
+    p.hot_x0 = 0;
+    p.hot_y0 = 0;
+    p.hot_w = p.tiles_x;
+    p.hot_h = p.tiles_y;
+    const double uu = (double)p.U.x * p.U.x + (double)p.U.y * p.U.y + (double)p.U.z * p.U.z;
+    const double vv = (double)p.V.x * p.V.x + (double)p.V.y * p.V.y + (double)p.V.z * p.V.z;
+    const double ww = (double)p.Wv.x * p.Wv.x + (double)p.Wv.y * p.Wv.y + (double)p.Wv.z * p.Wv.z;
+    if (!(uu > 0 && vv > 0 && ww > 0)) return;
+    double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+    for (int k = 0; k < 8; ++k) {
+        const double px = c->bounds[(k & 1) ? 3 : 0] - p.eye.x, py = c->bounds[(k & 2) ? 4 : 1] - p.eye.y, pz = c->bounds[(k & 4) ? 5 : 2] - p.eye.z;
+        const double a = (px * p.U.x + py * p.U.y + pz * p.U.z) / uu, b = (px * p.V.x + py * p.V.y + pz * p.V.z) / vv;
+        const double w = (px * p.Wv.x + py * p.Wv.y + pz * p.Wv.z) / ww;
+        if (!(w > 1e-6)) return;  // a corner beside or behind the eye: no useful rectangle
+        const double sx = (a / w + 1.0) * 0.5 * p.W, sy = (b / w + 1.0) * 0.5 * p.H;
+        x0 = sx < x0 ? sx : x0;
+        x1 = sx > x1 ? sx : x1;
+        y0 = sy < y0 ? sy : y0;
+        y1 = sy > y1 ? sy : y1;
+    }
+    // to window pixels, padded, clamped
+    auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    const uint32_t wx0 = (uint32_t)clampd(x0 - 2.0 - p.x0, 0.0, p.w), wx1 = (uint32_t)clampd(x1 + 3.0 - p.x0, 0.0, p.w);
+    const uint32_t wy0 = (uint32_t)clampd(y0 - 2.0 - p.y0, 0.0, p.h), wy1 = (uint32_t)clampd(y1 + 3.0 - p.y0, 0.0, p.h);
+    if (wx1 <= wx0 || wy1 <= wy0) {  // the scene is off screen: every tile is cheap
+        p.hot_w = p.hot_h = 0;
+        return;
+    }
+    const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
+    p.hot_x0 = wx0 / kTileW;
+    p.hot_w = (wx1 + kTileW - 1) / kTileW - p.hot_x0;
+    p.hot_y0 = lr0 / kTileH;
+    p.hot_h = (lr1 + kTileH - 1) / kTileH - p.hot_y0;
+    if (p.hot_x0 + p.hot_w > p.tiles_x) p.hot_w = p.tiles_x - p.hot_x0;
+    if (p.hot_y0 + p.hot_h > p.tiles_y) p.hot_h = p.tiles_y - p.hot_y0;
+    if (p.hot_w == 0 || p.hot_h == 0) p.hot_w = p.hot_h = 0;
+}
+
 extern "C" {
 
 uint32_t rtgo_abi_version(void) { return RTGO_ABI_VERSION; }
@@ -137,7 +190,7 @@ int rtgo_create(int device, rtgo_ctx** out)
     if (err == hipSuccess) err = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&c->d_lights, kMaxLights * sizeof(LightRec));
     if (err == hipSuccess) err = hipMemset(c->d_lights, 0, kMaxLights * sizeof(LightRec));
-    if (err == hipSuccess) err = hipMalloc(&c->d_meta, 4 * sizeof(int));
+    if (err == hipSuccess) err = hipMalloc(&c->d_meta, 16 * sizeof(int));
     // the megakernel may use most of the 160 KiB LDS of a CU
     const int max_lds = 160 * 1024;
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
@@ -227,13 +280,14 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), 0, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget, c->d_meta);
     RTGO_HIP(c, hipGetLastError());
-    int meta[3] = {0, 0, 0};
+    int meta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     const int depth = meta[0];
     c->lbvh_depth = depth;
     c->fast_depth = meta[1];
     c->n_small = meta[2];
+    std::memcpy(c->bounds, &meta[3], sizeof c->bounds);
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
                                                std::to_string(kStackDepth) + ")");
@@ -336,7 +390,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.local_rows = rtgo_local_rows(p.h, p.band_h, p.n_ranks, p.rank);
     if ((size_t)p.local_rows * p.w > c->pixels) return fail(c, RTGO_E_INVALID, "rtgo_launch: output buffer too small for this window");
     p.tiles_x = (p.w + kTileW - 1) / kTileW;
-    p.n_tiles = p.tiles_x * ((p.local_rows + kTileH - 1) / kTileH);
+    p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+    p.n_tiles = p.tiles_x * p.tiles_y;
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
     p.fnodes = c->d_fnodes;
@@ -361,6 +416,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.V = c->V;
     p.Wv = c->W;
     p.bg = c->bg;
+    hot_rectangle(c, p);
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.

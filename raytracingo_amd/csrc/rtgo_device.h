@@ -59,6 +59,8 @@ struct LaunchParams {
     unsigned int x0, y0, w, h;      // window
     unsigned int band_h, n_ranks, rank, local_rows;
     unsigned int tiles_x, n_tiles;
+    // tiles inside this rectangle (local tile coordinates) are handed out first: see tile_of()
+    unsigned int hot_x0, hot_y0, hot_w, hot_h, tiles_y;
     v3 eye, U, V, Wv, bg;
 };
 
@@ -598,6 +600,45 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v)
     return v;
 }
 
+// Queue index -> tile.  The tiles that can contain geometry (the screen rectangle of the scene's bounds, computed by the host)
+// come first, the empty ones last: an in-scene tile costs ~30x an empty one and a frame has only ~2 of them per resident
+// wave, so handing them out in raster order leaves a fifth of the waves idle behind the last expensive tiles; with the cheap
+// tiles at the end of the queue they fill that tail instead.
+__device__ __forceinline__ void tile_of(const LaunchParams& p, unsigned int idx, unsigned int& tx, unsigned int& ty)
+{
+    const unsigned int hot = p.hot_w * p.hot_h;
+    if (idx < hot) {
+        tx = p.hot_x0 + idx % p.hot_w;
+        ty = p.hot_y0 + idx / p.hot_w;
+        return;
+    }
+    unsigned int j = idx - hot;
+    const unsigned int below = p.hot_y0 * p.tiles_x;                              // full rows under the rectangle
+    if (j < below) {
+        tx = j % p.tiles_x;
+        ty = j / p.tiles_x;
+        return;
+    }
+    j -= below;
+    const unsigned int above = (p.tiles_y - p.hot_y0 - p.hot_h) * p.tiles_x;      // full rows over it
+    if (j < above) {
+        tx = j % p.tiles_x;
+        ty = p.hot_y0 + p.hot_h + j / p.tiles_x;
+        return;
+    }
+    j -= above;
+    const unsigned int left = p.hot_h * p.hot_x0;                                 // strip on its left
+    if (j < left) {
+        tx = j % p.hot_x0;
+        ty = p.hot_y0 + j / p.hot_x0;
+        return;
+    }
+    j -= left;
+    const unsigned int dw = p.tiles_x - p.hot_x0 - p.hot_w;                       // strip on its right
+    tx = p.hot_x0 + p.hot_w + j % dw;
+    ty = p.hot_y0 + j / dw;
+}
+
 // =====================================================================================================================
 // The render megakernel.  One wave = one 16x4 pixel tile pulled from a global queue (persistent workgroups); one lane =
 // one pixel.  Each loop iteration traces exactly ONE ray per live lane (primary, bounce or shadow), so lanes at different
@@ -654,7 +695,8 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= p.n_tiles) break;
 
-        const unsigned int tx = tile % p.tiles_x, ty = tile / p.tiles_x;
+        unsigned int tx, ty;
+        tile_of(p, tile, tx, ty);
         const unsigned int lx = tx * kTileW + (lane & (kTileW - 1));
         const unsigned int lr = ty * kTileH + (lane / kTileW);  // local (compact) row
         const bool in_range = lx < p.w && lr < p.local_rows;
@@ -1010,7 +1052,7 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
 // Outputs.  out_nodes: (2n-1) x 2 float4 canonical LBVH; out_prims: n x 6 float4 (SBT order); aabb_io: n x 6 floats (read when
 // have_aabb, else written); out_fnodes / out_fprims: the fast walk's tree (2*n_small-1 nodes) and Morton-ordered records
 // (small primitives first, then the "big" ones that are tested up front);
-// out_meta = {canonical depth, fast-walk stack depth, n_small}.
+// out_meta = {canonical depth, fast-walk stack depth, n_small, tight scene bounds (6 floats as bits)}.
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
@@ -1213,6 +1255,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     }
     __syncthreads();
     reduce_bounds(i < n);
+    if (i < 6) out_meta[3 + i] = __float_as_int(s_red[i][0]);  // tight scene bounds: min xyz, max xyz
     bool big = false;
     if (i < n) {
         int wide = 0;
