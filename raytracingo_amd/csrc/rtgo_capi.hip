@@ -100,10 +100,10 @@ static uint32_t owned_rows_below(uint32_t y, uint32_t band_h, uint32_t n_ranks, 
     return owned_full * band_h + ((full % n_ranks == rank) ? part : 0);
 }
 
-// Screen rectangle (in local tile coordinates) that can contain geometry: the 8 corners of the scene's tight bounds through
+// Screen rectangle (in unit coordinates: columns of unit_px pixels, local rows) that can contain geometry: the 8 corners of the scene's tight bounds through
 // the pinhole camera of the raygen program (d = dx*U + dy*V + W, kernel.cu:214-220).  Conservative: padded by a pixel, and
 // the whole window whenever a corner is not in front of the eye.  Only the ORDER in which tiles are handed out depends on it.
-static void hot_rectangle(const rtgo_ctx* c, LaunchParams& p)
+static void hot_rectangle(const rtgo_ctx* c, LaunchParams& p, uint32_t unit_px)
 {
     p.hot_x0 = 0;
     p.hot_y0 = 0;
@@ -134,10 +134,10 @@ static void hot_rectangle(const rtgo_ctx* c, LaunchParams& p)
         return;
     }
     const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
-    p.hot_x0 = wx0 / kTileW;
-    p.hot_w = (wx1 + kTileW - 1) / kTileW - p.hot_x0;
-    p.hot_y0 = lr0 / kTileH;
-    p.hot_h = (lr1 + kTileH - 1) / kTileH - p.hot_y0;
+    p.hot_x0 = wx0 / unit_px;
+    p.hot_w = (wx1 + unit_px - 1) / unit_px - p.hot_x0;
+    p.hot_y0 = lr0;
+    p.hot_h = lr1 - lr0;
     if (p.hot_x0 + p.hot_w > p.tiles_x) p.hot_w = p.tiles_x - p.hot_x0;
     if (p.hot_y0 + p.hot_h > p.tiles_y) p.hot_h = p.tiles_y - p.hot_y0;
     if (p.hot_w == 0 || p.hot_h == 0) p.hot_w = p.hot_h = 0;
@@ -185,7 +185,7 @@ int rtgo_create(int device, rtgo_ctx** out)
         err = hipEventCreate(&c->ev_start[i]);
         if (err == hipSuccess) err = hipEventCreate(&c->ev_stop[i]);
     }
-    if (err == hipSuccess) err = hipMalloc(&c->d_queue, sizeof(unsigned int));
+    if (err == hipSuccess) err = hipMalloc(&c->d_queue, kQueues * 16 * sizeof(unsigned int));
     if (err == hipSuccess) err = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&c->d_lights, kMaxLights * sizeof(LightRec));
@@ -389,8 +389,12 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (p.rank >= p.n_ranks) return fail(c, RTGO_E_INVALID, "rtgo_launch: rank >= n_ranks");
     p.local_rows = rtgo_local_rows(p.h, p.band_h, p.n_ranks, p.rank);
     if ((size_t)p.local_rows * p.w > c->pixels) return fail(c, RTGO_E_INVALID, "rtgo_launch: output buffer too small for this window");
-    p.tiles_x = (p.w + kTileW - 1) / kTileW;
-    p.tiles_y = (p.local_rows + kTileH - 1) / kTileH;
+    // scheduling units of 64 paths: the N*N samples of `unit_px` neighbouring pixels of one row (see render_kernel)
+    const uint32_t nn = (uint32_t)f->sqrt_spp * (uint32_t)f->sqrt_spp;
+    const uint32_t unit_px = 64u / (nn < (uint32_t)kSamplesPerPass ? nn : (uint32_t)kSamplesPerPass);
+    p.tiles_x = (p.w + unit_px - 1) / unit_px;
+    p.tiles_y = p.local_rows;
+    if ((uint64_t)p.tiles_x * p.tiles_y > 0xFFFFFF00ull) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: window too large");
     p.n_tiles = p.tiles_x * p.tiles_y;
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
@@ -416,7 +420,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.V = c->V;
     p.Wv = c->W;
     p.bg = c->bg;
-    hot_rectangle(c, p);
+    hot_rectangle(c, p, unit_px);
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
@@ -442,11 +446,18 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (best_waves == 0) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
     int cus = c->num_cus - (int)(f->reserve_cus < (uint32_t)c->num_cus / 2 ? f->reserve_cus : (uint32_t)c->num_cus / 2);
     unsigned int grid = (unsigned int)(cus * blocks_per_cu);
-    const unsigned int need = (p.n_tiles + (block / 64) - 1) / (block / 64);
+    // queue granularity: as coarse as kUnitsPerGrab units per atomic when there is plenty of work, finer when units are
+    // scarce (small windows, one GPU's share of a tiled frame) so that every resident wave still gets >= ~8 turns
+    const unsigned int waves_total = grid * (unsigned int)(block / 64);
+    unsigned int grab = p.n_tiles / (waves_total * 8u);
+    grab = grab < 1u ? 1u : (grab > (unsigned int)kUnitsPerGrab ? (unsigned int)kUnitsPerGrab : grab);
+    p.grab = grab;
+    const unsigned int grabs = (p.n_tiles + grab - 1) / grab;
+    const unsigned int need = (grabs + (block / 64) - 1) / (block / 64);
     if (grid > need) grid = need;
 
     RTGO_HIP(c, hipSetDevice(c->device));
-    RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, sizeof(unsigned int), c->stream));
+    RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, kQueues * 16 * sizeof(unsigned int), c->stream));
     if (c->ev_pending == rtgo_ctx::kEvRing) {
         int rc = harvest_events(c, 1);
         if (rc) return rc;

@@ -16,12 +16,11 @@ namespace rtgo {
 constexpr int kMaxBlock = 1024;      // workgroup = 256, 512 or 1024 threads: chosen per scene so that 16 waves fit a CU's LDS
 constexpr int kStackDepth = 24;      // per-lane traversal stack entries of the canonical walk (LBVH depth is checked against it at build)
 constexpr int kDefaultLeafBudget = 32;  // fast walk: LBVH subtrees whose leaf-test cost is <= this many rectangle tests become one leaf
-#ifndef RTGO_TILE_W
-#define RTGO_TILE_W 16
-#endif
-constexpr int kTileW = RTGO_TILE_W, kTileH = 64 / RTGO_TILE_W;  // one wave = 16x4 pixels: 256-byte float4 rows, 4-row bands for multi-GPU
 constexpr int kMaxPrims = 512;
 constexpr int kMaxLights = 10;
+constexpr int kSamplesPerPass = 16;   // samples of one pixel that run side by side (the in-order sum costs this many lane exchanges)
+constexpr int kQueues = 8;           // work-queue heads (one per XCD label)
+constexpr int kUnitsPerGrab = 8;     // most units (64 paths each) a wave takes from the queue per atomic
 constexpr int kMaxLevels = 5;        // bounce records kept per path (maxTraceDepth <= 5)
 constexpr float kPi = 3.14159265358979323846f;  // M_PIf, sutil/vec_math.h:43
 
@@ -49,7 +48,7 @@ struct LaunchParams {
     const LightRec* lights;
     float4* accum;
     uchar4* image;
-    unsigned int* queue;            // tile queue head (zeroed before every launch)
+    unsigned int* queue;            // kQueues work-queue heads, 16 words apart (zeroed before every launch)
     unsigned long long* counters;   // [0] rays_total [1] rays_occlusion [2] node_visits [3] prim_tests [4] hits
     int n_prims, n_nodes, n_lights;
     unsigned int W, H;              // full image
@@ -58,9 +57,10 @@ struct LaunchParams {
     int ambient;
     unsigned int x0, y0, w, h;      // window
     unsigned int band_h, n_ranks, rank, local_rows;
-    unsigned int tiles_x, n_tiles;
+    unsigned int tiles_x, n_tiles;   // scheduling units per local row, units in this launch
     // tiles inside this rectangle (local tile coordinates) are handed out first: see tile_of()
     unsigned int hot_x0, hot_y0, hot_w, hot_h, tiles_y;
+    unsigned int grab;               // units a wave takes from the queue per atomic (1..kUnitsPerGrab)
     v3 eye, U, V, Wv, bg;
 };
 
@@ -94,6 +94,21 @@ __device__ __forceinline__ unsigned int tea16(unsigned int v0, unsigned int v1)
         v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
     }
     return v0;
+}
+// the LCG advanced by m draws in O(log m): f(s) = a*s + c, f^m(s) = A*s + C by repeated squaring of the affine map
+__device__ __forceinline__ unsigned int lcg_skip(unsigned int s, unsigned int m)
+{
+    unsigned int A = 1u, C = 0u, a = 1664525u, c = 1013904223u;
+    while (m) {
+        if (m & 1u) {
+            A = A * a;
+            C = C * a + c;
+        }
+        c = (a + 1u) * c;
+        a = a * a;
+        m >>= 1;
+    }
+    return A * s + C;
 }
 __device__ __forceinline__ float rnd(unsigned int& prev)
 {
@@ -686,44 +701,84 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
     const unsigned int nn = (unsigned int)(p.sqrt_spp * p.sqrt_spp);
     const float inc = 1.0f / (float)p.sqrt_spp;
     const float dimX = (float)p.W, dimY = (float)p.H;
+    // Work decomposition: ONE LANE = ONE PATH.  A wave takes "units" of 64/nn_eff neighbouring pixels of a row and runs
+    // nn_eff = min(nn, 16) samples of each side by side, in ceil(nn / nn_eff) passes.  The samples of a pixel are independent
+    // given the LCG state their jitter starts from (trace passes the seed by value, kernel.cu:46-79), which is the pixel's
+    // tea<16> seed advanced by 2k draws; their results are then summed IN SAMPLE ORDER (kernel.cu:232), so the pixel is bit
+    // for bit what the reference's sequential loop gives.  Against one-lane-per-pixel this keeps the 64 lanes at the same
+    // bounce, and makes the unit of scheduling 16x smaller at 16 spp (the frame has only ~2 in-scene 64-pixel tiles per
+    // resident wave: whole waves idle behind the last ones, and with the frame split over 8 GPUs most waves never get one).
+    const unsigned int nn_eff = nn < (unsigned int)kSamplesPerPass ? nn : (unsigned int)kSamplesPerPass;  // samples of one pixel that share a pass
+    const unsigned int P = 64u / nn_eff;                        // pixels per unit
+    const unsigned int passes = (nn + nn_eff - 1u) / nn_eff;
+    const unsigned int pl = (unsigned int)lane / nn_eff;        // this lane's pixel within the unit
+    const unsigned int kl = (unsigned int)lane - pl * nn_eff;   // this lane's sample within the pass
+    const unsigned int group_base = (pl < P ? pl : 0u) * nn_eff;
 
     unsigned int c_rays = 0, c_occl = 0, c_nodes = 0, c_tests = 0, c_hits = 0;
 
+    // Work queue: kQueues heads, 64 bytes apart; head q serves the units u with u % kQueues == q.  A wave pulls from the head
+    // of its workgroup's label (blockIdx % 8: workgroups b and b+8 share an XCD) and, when that runs dry, from the others.
+    // One head saturates at ~88 dequeues/us chip-wide (MI355X_MICROARCH "dequeue"), which a frame of 64-path units reaches;
+    // eight heads on different lines do not.  Results do not depend on who takes what.
+    unsigned int q = blockIdx.x % (unsigned int)kQueues;
+    unsigned int dry = 0;   // consecutive queues found empty
+    // the pull for the NEXT grab is issued before the current one is processed, so its ~1-2 us round trip hides behind work
+    unsigned int pending = 0;
+    if (lane == 0) pending = atomicAdd(p.queue + 16u * q, p.grab);
     for (;;) {
-        unsigned int tile = 0;
-        if (lane == 0) tile = atomicAdd(p.queue, 1u);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= p.n_tiles) break;
-
-        unsigned int tx, ty;
-        tile_of(p, tile, tx, ty);
-        const unsigned int lx = tx * kTileW + (lane & (kTileW - 1));
-        const unsigned int lr = ty * kTileH + (lane / kTileW);  // local (compact) row
-        const bool in_range = lx < p.w && lr < p.local_rows;
+        const unsigned int q_count = (p.n_tiles + (unsigned int)kQueues - 1u - q) / (unsigned int)kQueues;   // units in queue q
+        const unsigned int first = __builtin_amdgcn_readfirstlane(pending);
+        if (first >= q_count) {
+            if (++dry == (unsigned int)kQueues) break;   // every head is past its end: the grid drains
+            q = (q + 1u) % (unsigned int)kQueues;
+            if (lane == 0) pending = atomicAdd(p.queue + 16u * q, p.grab);
+            continue;
+        }
+        if (lane == 0) pending = atomicAdd(p.queue + 16u * q, p.grab);
+        dry = 0;
+#pragma unroll 1
+        for (unsigned int ui = 0; ui < p.grab; ++ui) {
+        if (first + ui >= q_count) break;
+        const unsigned int unit = (first + ui) * (unsigned int)kQueues + q;
+        unsigned int ux, lr;   // unit column, local (compact) row
+        tile_of(p, unit, ux, lr);
+        const unsigned int lx = ux * P + pl;
+        const bool in_range = pl < P && lx < p.w;
         // local row -> window row under the band interleave
         const unsigned int band = lr / p.band_h;
         const unsigned int wrow = (band * p.n_ranks + p.rank) * p.band_h + (lr - band * p.band_h);
         const unsigned int gx = p.x0 + lx, gy = p.y0 + wrow;
         const float fx = (float)gx, fy = (float)gy;
 
-        // __raygen__rg state (kernel.cu:184-247)
-        unsigned int pix_seed = tea16(p.W * gy + gx, p.frame);
+        // __raygen__rg (kernel.cu:184-247)
+        const unsigned int pix0 = tea16(p.W * gy + gx, p.frame);
         v3 color = mk(0.0f, 0.0f, 0.0f);
-        unsigned int s = 0;            // next sample to start
-        bool alive = in_range;         // lane still has samples to finish
-        bool in_path = false;
+#pragma unroll 1
+        for (unsigned int pass = 0; pass < passes; ++pass) {
+        const unsigned int k = pass * nn_eff + kl;   // sample index: i-major, k = i*N + j (kernel.cu:206-208)
+        bool active = in_range && k < nn;
         int depth = 0;
         int phase = 0;                 // distributed mode: 0 = radiance ray in flight, 1 = shadow ray in flight
-        unsigned int seed = 0;
-        v3 ro = mk(0, 0, 0), rd = mk(0, 0, 1);
-        float tmin = 0.0f, tmax = 0.0f;
+        // start sample k: kernel.cu:210-231; x jitter drawn first.  Draws 2k and 2k+1 of the pixel's stream.
+        unsigned int seed = lcg_skip(pix0, 2u * k);
+        const unsigned int si = k / (unsigned int)p.sqrt_spp, sj = k - si * (unsigned int)p.sqrt_spp;
+        const float r0 = rnd(seed);
+        const float r1 = rnd(seed);
+        const float dx = 2.0f * ((fx + ((float)si + r0) * inc) / dimX) - 1.0f;
+        const float dy = 2.0f * ((fy + ((float)sj + r1) * inc) / dimY) - 1.0f;
+        v3 ro = p.eye;
+        v3 rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.Wv));
+        float tmin = 0.05f, tmax = 1e16f;
+        v3 result = mk(0.0f, 0.0f, 0.0f);   // payload of this sample's primary ray
+        bool any_hit = false;
         // per-level records, folded innermost-first when the path ends
         v3 lvA[kMaxLevels];            // PATH: w_k = dot(N,Ra)*kd ; distributed: a_k = falloff*diffuse
         int lvPrim[kMaxLevels];        // distributed: primitive of level k (kr, kd re-read at fold time)
 #pragma unroll
-        for (int k = 0; k < kMaxLevels; ++k) {
-            lvA[k] = mk(0, 0, 0);
-            lvPrim[k] = 0;
+        for (int q = 0; q < kMaxLevels; ++q) {
+            lvA[q] = mk(0, 0, 0);
+            lvPrim[q] = 0;
         }
         // distributed: state kept across the shadow ray
         v3 sN = mk(0, 0, 0), sRr = mk(0, 0, 0);
@@ -731,38 +786,15 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
         int sPrim = 0, sLight = 0;
         bool sNVneg = false;
 
-        while (__ballot(alive) != 0ull) {
-#ifndef RTGO_REGEN_THRESHOLD
-#define RTGO_REGEN_THRESHOLD 16
-#endif
-            // lanes whose path has ended wait until at least RTGO_REGEN_THRESHOLD lanes are waiting (1 = regenerate at once)
-            const int waiting = __popcll(__ballot(alive && !in_path));
-            const int running = __popcll(__ballot(alive && in_path));
-            const bool regen = waiting >= RTGO_REGEN_THRESHOLD || running == 0;
-            if (regen && alive && !in_path) {
-                // start sample s: kernel.cu:206-231.  i-major order, x jitter drawn first
-                const unsigned int i = s / (unsigned int)p.sqrt_spp, j = s - i * (unsigned int)p.sqrt_spp;
-                const float r0 = rnd(pix_seed);
-                const float r1 = rnd(pix_seed);
-                const float dx = 2.0f * ((fx + ((float)i + r0) * inc) / dimX) - 1.0f;
-                const float dy = 2.0f * ((fy + ((float)j + r1) * inc) / dimY) - 1.0f;
-                ro = p.eye;
-                rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.Wv));
-                tmin = 0.05f;
-                tmax = 1e16f;
-                depth = 0;
-                phase = 0;
-                seed = pix_seed;
-                in_path = true;
-                ++s;
-            }
-            if (alive && in_path) {
+        while (__ballot(active) != 0ull) {
+            if (active) {
                 Hit h;
                 c_rays += 1;
                 bool hit;
                 if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
                 else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h, c_nodes, c_tests);
                 if (STATS && hit) c_hits += 1;
+                any_hit = any_hit || hit;
 
                 bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
                 v3 term = mk(0, 0, 0);
@@ -905,14 +937,25 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
                             }
                         }
                     }
-                    color = vadd(color, term);
-                    in_path = false;
-                    if (s == nn) alive = false;
+                    result = term;
+                    active = false;
                 }
             }
         }
+        // color += payload, in sample order (kernel.cu:232): every lane of a pixel's group walks the group's results
+        const unsigned int cnt = (nn - pass * nn_eff) < nn_eff ? (nn - pass * nn_eff) : nn_eff;
+        if (__ballot(any_hit) == 0ull) {
+            // every primary ray of the unit missed: all payloads are the background colour, no lane exchange needed
+            for (unsigned int q = 0; q < cnt; ++q) color = vadd(color, p.bg);
+        } else {
+            for (unsigned int q = 0; q < cnt; ++q) {
+                const int src = (int)(group_base + q);
+                color = vadd(color, mk(__shfl(result.x, src, 64), __shfl(result.y, src, 64), __shfl(result.z, src, 64)));
+            }
+        }
+        }  // pass
 
-        if (in_range) {
+        if (in_range && kl == 0) {
             // kernel.cu:236-246.  float3 / float multiplies by the reciprocal (vec_math.h:479-483)
             v3 cur = vscale(color, 1.0f / (float)nn);
             const size_t idx = (size_t)lr * p.w + lx;
@@ -928,6 +971,7 @@ __global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p,
                                        (unsigned char)(clampf(cur.y, 0.0f, 1.0f) * 255.0f),
                                        (unsigned char)(clampf(cur.z, 0.0f, 1.0f) * 255.0f), 255u);
         }
+        }  // unit
     }
 
     // one atomic per wave per counter

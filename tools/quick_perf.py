@@ -10,12 +10,15 @@ W = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 N = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 path = (sys.argv[5] if len(sys.argv) > 5 else "path") == "path"
+G, g = [int(x) for x in os.environ.get("BANDS", "1,0").split(",")]   # render only rank g's share of a G-way band split
 t = hscene.tables(name, W, H)
 ctx = capi.Context(0)
 ctx.set_scene(t["type"], t["M"], t["mat"], t["aabb"])
 ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
 ctx.set_background(t["bg"]); ctx.set_lights(t["lights"])
 ctx.resize(W * H)
+_mk = capi.make_frame
+capi.make_frame = lambda *a, **k: _mk(*a, bands=(4, G, g), **k)
 for f in range(3):
     ctx.launch(capi.make_frame(W, H, N, f, path)); ctx.sync()
 ctx.reset_stats()
