@@ -193,10 +193,11 @@ int rtgo_create(int device, rtgo_ctx** out)
     if (err == hipSuccess) err = hipMalloc(&c->d_meta, 16 * sizeof(int));
     // the megakernel may use most of the 160 KiB LDS of a CU
     const int max_lds = 160 * 1024;
-    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)render_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    const void* kernels[6] = {(const void*)render_kernel<true, false, 4>,  (const void*)render_kernel<true, false, 5>,
+                              (const void*)render_kernel<false, false, 4>, (const void*)render_kernel<false, false, 5>,
+                              (const void*)render_kernel<true, true, 4>,   (const void*)render_kernel<false, true, 4>};
+    for (const void* k : kernels)
+        if (err == hipSuccess) err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (err == hipSuccess) err = hipDeviceSynchronize();  // the null-stream memsets above must land before any launch
     if (err != hipSuccess) {
         std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
@@ -429,20 +430,22 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int fast_nodes = c->n_small > 0 ? 2 * c->n_small - 1 : 0;
     const size_t scene_lds = (size_t)(2 * (stats ? p.n_nodes : fast_nodes) + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
                              (size_t)kMaxLights * sizeof(LightRec);
-    int block = 0, blocks_per_cu = 0, best_waves = 0;
+    int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
     size_t lds = 0;
-    for (int b = 256; b <= kMaxBlock; b *= 2) {
-        const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2);
-        int per_cu = (int)((160 * 1024) / l);
-        if (per_cu * (b / 64) > 16) per_cu = 16 / (b / 64);
-        const int waves = per_cu * (b / 64);
-        if (waves > best_waves) {
-            best_waves = waves;
-            block = b;
-            blocks_per_cu = per_cu;
-            lds = l;
+    for (int w = 4; w <= (stats ? 4 : 5); ++w)   // waves per SIMD the kernel variant is compiled for
+        for (int b = 256; b <= kMaxBlock; b *= 2) {
+            const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2);
+            int per_cu = (int)((160 * 1024) / l);
+            if (per_cu * (b / 64) > 4 * w) per_cu = (4 * w) / (b / 64);
+            const int waves = per_cu * (b / 64);
+            if (waves > best_waves) {
+                best_waves = waves;
+                block = b;
+                blocks_per_cu = per_cu;
+                lds = l;
+                wpe = w;
+            }
         }
-    }
     if (best_waves == 0) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
     int cus = c->num_cus - (int)(f->reserve_cus < (uint32_t)c->num_cus / 2 ? f->reserve_cus : (uint32_t)c->num_cus / 2);
     unsigned int grid = (unsigned int)(cus * blocks_per_cu);
@@ -464,10 +467,13 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    if (path && !stats) hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
-    else if (path && stats) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
-    else if (!path && !stats) hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
-    else hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(block), lds, c->stream, p, (const float4*)c->d_fprims);
+    const float4* fp = (const float4*)c->d_fprims;
+    if (path && stats) hipLaunchKernelGGL((render_kernel<true, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    else if (!path && stats) hipLaunchKernelGGL((render_kernel<false, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    else if (path && wpe == 5) hipLaunchKernelGGL((render_kernel<true, false, 5>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    else if (path) hipLaunchKernelGGL((render_kernel<true, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    else if (wpe == 5) hipLaunchKernelGGL((render_kernel<false, false, 5>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    else hipLaunchKernelGGL((render_kernel<false, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;

@@ -661,8 +661,10 @@ __device__ __forceinline__ void tile_of(const LaunchParams& p, unsigned int idx,
 // keeps the sample sum in the reference's order (kernel.cu:206-236).
 // PATH = Params::enablePathTracing.  STATS adds the V/T/h counters used for the roofline's algorithmic bytes.
 // =====================================================================================================================
-template <bool PATH, bool STATS>
-__global__ __launch_bounds__(kMaxBlock) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
+// WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs, no spills) for scenes whose LDS image limits a CU to
+// 16 waves anyway, 5 (<= 96 VGPRs, a few spilled dwords) for small scenes, where the fifth wave buys more than the spills cost.
+template <bool PATH, bool STATS, int WPE>
+__global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
