@@ -390,10 +390,22 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (p.rank >= p.n_ranks) return fail(c, RTGO_E_INVALID, "rtgo_launch: rank >= n_ranks");
     p.local_rows = rtgo_local_rows(p.h, p.band_h, p.n_ranks, p.rank);
     if ((size_t)p.local_rows * p.w > c->pixels) return fail(c, RTGO_E_INVALID, "rtgo_launch: output buffer too small for this window");
-    // scheduling units of 64 paths: the N*N samples of `unit_px` neighbouring pixels of one row (see render_kernel)
+    // scheduling: units of 64 paths = the N*N samples of `unit_px` neighbouring pixels of one row; the queue hands out STRIPS of
+    // `grab` units side by side (<= 64 pixels).  Strips are long when there is plenty of work (their pixel seeds are hashed once
+    // per strip) and short when units are scarce (small windows, one GPU's share of a tiled frame), so that every resident
+    // wave still gets >= ~8 turns.  The final grab is set below, once the grid is known.
     const uint32_t nn = (uint32_t)f->sqrt_spp * (uint32_t)f->sqrt_spp;
     const uint32_t unit_px = 64u / (nn < (uint32_t)kSamplesPerPass ? nn : (uint32_t)kSamplesPerPass);
-    p.tiles_x = (p.w + unit_px - 1) / unit_px;
+    const uint64_t units_total = (uint64_t)((p.w + unit_px - 1) / unit_px) * p.local_rows;
+    {
+        const uint64_t waves_guess = (uint64_t)c->num_cus * 16u;
+        uint32_t grab = (uint32_t)(units_total / (waves_guess * 8u));
+        const uint32_t grab_max = (64u / unit_px) < (uint32_t)kUnitsPerGrab ? (64u / unit_px) : (uint32_t)kUnitsPerGrab;
+        grab = grab < 1u ? 1u : (grab > grab_max ? grab_max : grab);
+        p.grab = grab;
+    }
+    const uint32_t strip_px = unit_px * p.grab;
+    p.tiles_x = (p.w + strip_px - 1) / strip_px;
     p.tiles_y = p.local_rows;
     if ((uint64_t)p.tiles_x * p.tiles_y > 0xFFFFFF00ull) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: window too large");
     p.n_tiles = p.tiles_x * p.tiles_y;
@@ -421,7 +433,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.V = c->V;
     p.Wv = c->W;
     p.bg = c->bg;
-    hot_rectangle(c, p, unit_px);
+    hot_rectangle(c, p, strip_px);
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
@@ -449,14 +461,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (best_waves == 0) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: scene does not fit in LDS");
     int cus = c->num_cus - (int)(f->reserve_cus < (uint32_t)c->num_cus / 2 ? f->reserve_cus : (uint32_t)c->num_cus / 2);
     unsigned int grid = (unsigned int)(cus * blocks_per_cu);
-    // queue granularity: as coarse as kUnitsPerGrab units per atomic when there is plenty of work, finer when units are
-    // scarce (small windows, one GPU's share of a tiled frame) so that every resident wave still gets >= ~8 turns
-    const unsigned int waves_total = grid * (unsigned int)(block / 64);
-    unsigned int grab = p.n_tiles / (waves_total * 8u);
-    grab = grab < 1u ? 1u : (grab > (unsigned int)kUnitsPerGrab ? (unsigned int)kUnitsPerGrab : grab);
-    p.grab = grab;
-    const unsigned int grabs = (p.n_tiles + grab - 1) / grab;
-    const unsigned int need = (grabs + (block / 64) - 1) / (block / 64);
+    const unsigned int need = (p.n_tiles + (block / 64) - 1) / (block / 64);
     if (grid > need) grid = need;
 
     RTGO_HIP(c, hipSetDevice(c->device));

@@ -20,7 +20,7 @@ constexpr int kMaxPrims = 512;
 constexpr int kMaxLights = 10;
 constexpr int kSamplesPerPass = 16;   // samples of one pixel that run side by side (the in-order sum costs this many lane exchanges)
 constexpr int kQueues = 8;           // work-queue heads (one per XCD label)
-constexpr int kUnitsPerGrab = 8;     // most units (64 paths each) a wave takes from the queue per atomic
+constexpr int kUnitsPerGrab = 4;     // most units (64 paths each) in one strip = one queue entry (longer strips: seeds cheaper, balance worse)
 constexpr int kMaxLevels = 5;        // bounce records kept per path (maxTraceDepth <= 5)
 constexpr float kPi = 3.14159265358979323846f;  // M_PIf, sutil/vec_math.h:43
 
@@ -57,10 +57,10 @@ struct LaunchParams {
     int ambient;
     unsigned int x0, y0, w, h;      // window
     unsigned int band_h, n_ranks, rank, local_rows;
-    unsigned int tiles_x, n_tiles;   // scheduling units per local row, units in this launch
+    unsigned int tiles_x, n_tiles;   // strips per local row, strips in this launch
     // tiles inside this rectangle (local tile coordinates) are handed out first: see tile_of()
     unsigned int hot_x0, hot_y0, hot_w, hot_h, tiles_y;
-    unsigned int grab;               // units a wave takes from the queue per atomic (1..kUnitsPerGrab)
+    unsigned int grab;               // units per strip (1..kUnitsPerGrab, strip <= 64 pixels)
     v3 eye, U, V, Wv, bg;
 };
 
@@ -727,34 +727,41 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     unsigned int dry = 0;   // consecutive queues found empty
     // the pull for the NEXT grab is issued before the current one is processed, so its ~1-2 us round trip hides behind work
     unsigned int pending = 0;
-    if (lane == 0) pending = atomicAdd(p.queue + 16u * q, p.grab);
+    if (lane == 0) pending = atomicAdd(p.queue + 16u * q, 1u);
     for (;;) {
         const unsigned int q_count = (p.n_tiles + (unsigned int)kQueues - 1u - q) / (unsigned int)kQueues;   // units in queue q
         const unsigned int first = __builtin_amdgcn_readfirstlane(pending);
         if (first >= q_count) {
             if (++dry == (unsigned int)kQueues) break;   // every head is past its end: the grid drains
             q = (q + 1u) % (unsigned int)kQueues;
-            if (lane == 0) pending = atomicAdd(p.queue + 16u * q, p.grab);
+            if (lane == 0) pending = atomicAdd(p.queue + 16u * q, 1u);
             continue;
         }
-        if (lane == 0) pending = atomicAdd(p.queue + 16u * q, p.grab);
+        if (lane == 0) pending = atomicAdd(p.queue + 16u * q, 1u);
         dry = 0;
-#pragma unroll 1
-        for (unsigned int ui = 0; ui < p.grab; ++ui) {
-        if (first + ui >= q_count) break;
-        const unsigned int unit = (first + ui) * (unsigned int)kQueues + q;
-        unsigned int ux, lr;   // unit column, local (compact) row
-        tile_of(p, unit, ux, lr);
-        const unsigned int lx = ux * P + pl;
-        const bool in_range = pl < P && lx < p.w;
+        // one queue entry = one STRIP: p.grab units side by side on a row (at most 64 pixels).  The strip's tea<16> pixel seeds
+        // are computed once, one pixel per lane (the hash is 16 dependent rounds: ~160 instructions whether 4 or 64 lanes need
+        // it), and handed to the units by lane exchange.
+        const unsigned int strip = first * (unsigned int)kQueues + q;
+        unsigned int sx, lr;   // strip column, local (compact) row
+        tile_of(p, strip, sx, lr);
         // local row -> window row under the band interleave
         const unsigned int band = lr / p.band_h;
         const unsigned int wrow = (band * p.n_ranks + p.rank) * p.band_h + (lr - band * p.band_h);
-        const unsigned int gx = p.x0 + lx, gy = p.y0 + wrow;
-        const float fx = (float)gx, fy = (float)gy;
+        const unsigned int gy = p.y0 + wrow;
+        const float fy = (float)gy;
+        const unsigned int strip_x0 = sx * p.grab * P;
+        const unsigned int strip_seed = tea16(p.W * gy + (p.x0 + strip_x0 + (unsigned int)lane), p.frame);
+#pragma unroll 1
+        for (unsigned int ui = 0; ui < p.grab; ++ui) {
+        const unsigned int lx = strip_x0 + ui * P + pl;
+        if (strip_x0 + ui * P >= p.w) break;
+        const bool in_range = pl < P && lx < p.w;
+        const unsigned int gx = p.x0 + lx;
+        const float fx = (float)gx;
 
         // __raygen__rg (kernel.cu:184-247)
-        const unsigned int pix0 = tea16(p.W * gy + gx, p.frame);
+        const unsigned int pix0 = (unsigned int)__shfl((int)strip_seed, (int)((ui * P + pl) & 63u), 64);
         v3 color = mk(0.0f, 0.0f, 0.0f);
 #pragma unroll 1
         for (unsigned int pass = 0; pass < passes; ++pass) {
