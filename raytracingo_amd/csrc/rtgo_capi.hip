@@ -446,7 +446,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     size_t lds = 0;
     for (int w = 4; w <= (stats ? 4 : 5); ++w)   // waves per SIMD the kernel variant is compiled for
         for (int b = 256; b <= kMaxBlock; b *= 2) {
-            const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2);
+            const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2) + (w == 5 ? (size_t)b * 4 * kMaxLevels * sizeof(float) : 0);
             int per_cu = (int)((160 * 1024) / l);
             if (per_cu * (b / 64) > 4 * w) per_cu = (4 * w) / (b / 64);
             const int waves = per_cu * (b / 64);

@@ -681,6 +681,10 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     const int bshift = 31 - __clz(kBlock);        // per-lane stack entry e lives at [e << bshift]
     LightRec* s_lights = reinterpret_cast<LightRec*>(s_stack_base + stack_depth * kBlock);
     const float4* s_mat = s_mat_w;
+    // small scenes (the 5-waves-per-SIMD variant): per-level path records live in LDS, [4 words x kMaxLevels][lane], instead of
+    // 15-20 VGPRs -- that is what lets the allocation fit 96 registers without spilling to scratch
+    constexpr bool LVLDS = (WPE == 5);
+    float* s_lv = reinterpret_cast<float*>(s_lights + kMaxLights) + threadIdx.x;
 
     const int tid = threadIdx.x;
     if (STATS) {
@@ -833,9 +837,15 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         } else if (depth < p.max_depth) {
                             const v3 Ra = hemisphere(N, N, 0.0f, seed);
                             const v3 wk = vadd(mk(0.0f, 0.0f, 0.0f), vscale(mk(m3.x, m3.y, m3.z), vdot(N, Ra)));
+                            if constexpr (LVLDS) {
+                                s_lv[(depth * 4 + 0) << bshift] = wk.x;
+                                s_lv[(depth * 4 + 1) << bshift] = wk.y;
+                                s_lv[(depth * 4 + 2) << bshift] = wk.z;
+                            } else {
 #pragma unroll
-                            for (int k = 0; k < kMaxLevels; ++k)
-                                if (k == depth) lvA[k] = wk;
+                                for (int k = 0; k < kMaxLevels; ++k)
+                                    if (k == depth) lvA[k] = wk;
+                            }
                             ++depth;
                             ro = x;
                             rd = Ra;
@@ -880,12 +890,19 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                             }
                         }
                         if (bounce) {
+                            if constexpr (LVLDS) {
+                                s_lv[(depth * 4 + 0) << bshift] = a.x;
+                                s_lv[(depth * 4 + 1) << bshift] = a.y;
+                                s_lv[(depth * 4 + 2) << bshift] = a.z;
+                                s_lv[(depth * 4 + 3) << bshift] = __int_as_float(sPrim);
+                            } else {
 #pragma unroll
-                            for (int k = 0; k < kMaxLevels; ++k)
-                                if (k == depth) {
-                                    lvA[k] = a;
-                                    lvPrim[k] = sPrim;
-                                }
+                                for (int k = 0; k < kMaxLevels; ++k)
+                                    if (k == depth) {
+                                        lvA[k] = a;
+                                        lvPrim[k] = sPrim;
+                                    }
+                            }
                             ++depth;
                             rd = r;            // ro = x and tmin = rayEpsilon are still those of the shadow ray
                             tmax = 1e6f;
@@ -940,15 +957,29 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 
                 if (done) {
                     // fold the level records innermost-first: kernel.cu:471-472 (path), :504,519,531 (distributed)
-#pragma unroll
-                    for (int k = kMaxLevels - 1; k >= 0; --k) {
-                        if (k < depth) {
+                    if constexpr (LVLDS) {
+                        for (int k = depth - 1; k >= 0; --k) {
+                            const v3 a = mk(s_lv[(k * 4 + 0) << bshift], s_lv[(k * 4 + 1) << bshift], s_lv[(k * 4 + 2) << bshift]);
                             if (PATH) {
-                                term = vmul(lvA[k], term);
+                                term = vmul(a, term);
                             } else {
-                                const float4 m3 = s_mat[MS * lvPrim[k] + 0], m4 = s_mat[MS * lvPrim[k] + 1];
-                                term = vadd(lvA[k], vmul(mk(m4.x, m4.y, m4.z), term));
+                                const int prim = __float_as_int(s_lv[(k * 4 + 3) << bshift]);
+                                const float4 m3 = s_mat[MS * prim + 0], m4 = s_mat[MS * prim + 1];
+                                term = vadd(a, vmul(mk(m4.x, m4.y, m4.z), term));
                                 if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = kMaxLevels - 1; k >= 0; --k) {
+                            if (k < depth) {
+                                if (PATH) {
+                                    term = vmul(lvA[k], term);
+                                } else {
+                                    const float4 m3 = s_mat[MS * lvPrim[k] + 0], m4 = s_mat[MS * lvPrim[k] + 1];
+                                    term = vadd(lvA[k], vmul(mk(m4.x, m4.y, m4.z), term));
+                                    if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
+                                }
                             }
                         }
                     }

@@ -2,7 +2,7 @@
 import collections, csv, glob, json, os, sys
 
 d, tag = sys.argv[1], sys.argv[2]
-KERNEL = "render_kernel<true, false>"
+KERNEL = "render_kernel<true, false"   # any register-budget variant of the timed path-mode kernel
 out = {"tag": tag, "kernel": "rtgo::" + KERNEL}
 try:
     out["bench"] = json.loads([l for l in open(os.path.join(d, "bench.json")) if l.startswith("{")][-1])
