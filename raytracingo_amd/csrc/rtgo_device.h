@@ -15,7 +15,7 @@ namespace rtgo {
 
 constexpr int kMaxBlock = 1024;      // workgroup = 256, 512 or 1024 threads: chosen per scene so that 16 waves fit a CU's LDS
 constexpr int kStackDepth = 24;      // per-lane traversal stack entries of the canonical walk (LBVH depth is checked against it at build)
-constexpr int kDefaultLeafBudget = 32;  // fast walk: LBVH subtrees whose leaf-test cost is <= this many rectangle tests become one leaf
+constexpr int kDefaultLeafBudget = 6;   // fast walk: LBVH subtrees whose leaf-test cost is <= this many rectangle tests become one leaf (6 = one cube)
 constexpr int kMaxPrims = 512;
 constexpr int kMaxLights = 10;
 constexpr int kSamplesPerPass = 16;   // samples of one pixel that run side by side (the in-order sum costs this many lane exchanges)
