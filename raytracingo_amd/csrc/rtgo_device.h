@@ -58,7 +58,7 @@ struct LaunchParams {
     unsigned int x0, y0, w, h;      // window
     unsigned int band_h, n_ranks, rank, local_rows;
     unsigned int tiles_x, n_tiles;   // strips per local row, strips in this launch
-    // tiles inside this rectangle (local tile coordinates) are handed out first: see tile_of()
+    // strips inside this rectangle (strip column, local row) are handed out first: see tile_of()
     unsigned int hot_x0, hot_y0, hot_w, hot_h, tiles_y;
     unsigned int grab;               // units per strip (1..kUnitsPerGrab, strip <= 64 pixels)
     v3 eye, U, V, Wv, bg;
@@ -615,10 +615,10 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v)
     return v;
 }
 
-// Queue index -> tile.  The tiles that can contain geometry (the screen rectangle of the scene's bounds, computed by the host)
-// come first, the empty ones last: an in-scene tile costs ~30x an empty one and a frame has only ~2 of them per resident
-// wave, so handing them out in raster order leaves a fifth of the waves idle behind the last expensive tiles; with the cheap
-// tiles at the end of the queue they fill that tail instead.
+// Queue index -> strip (column, local row).  The strips that can contain geometry (the screen rectangle of the scene's bounds,
+// computed by the host) come first, the empty ones last: an in-scene strip costs ~10x an empty one, so handing them out in
+// raster order leaves waves idle behind the last expensive strips; with the cheap ones at the end of the queue they fill
+// that tail instead.
 __device__ __forceinline__ void tile_of(const LaunchParams& p, unsigned int idx, unsigned int& tx, unsigned int& ty)
 {
     const unsigned int hot = p.hot_w * p.hot_h;
@@ -655,11 +655,11 @@ __device__ __forceinline__ void tile_of(const LaunchParams& p, unsigned int idx,
 }
 
 // =====================================================================================================================
-// The render megakernel.  One wave = one 16x4 pixel tile pulled from a global queue (persistent workgroups); one lane =
-// one pixel.  Each loop iteration traces exactly ONE ray per live lane (primary, bounce or shadow), so lanes at different
-// depths / samples share the same traversal code; a lane whose path ends regenerates its next sample in place, which
-// keeps the sample sum in the reference's order (kernel.cu:206-236).
-// PATH = Params::enablePathTracing.  STATS adds the V/T/h counters used for the roofline's algorithmic bytes.
+// The render megakernel.  Persistent workgroups; one lane = one PATH (see the decomposition note inside); each loop iteration
+// traces exactly ONE ray per live lane (primary, bounce or shadow), so the 64 lanes of a wave stay at the same bounce and
+// share the traversal and shading code.  Replaces __raygen__rg + optixTrace + the closest-hit/miss programs of kernel.cu.
+// PATH = Params::enablePathTracing.  STATS = false: the fast walk (timed kernel).  STATS = true: the canonical LBVH walk with
+// the V/T/h counters that define the roofline's algorithmic bytes; both produce the same pixels bit for bit.
 // =====================================================================================================================
 // WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs, no spills) for scenes whose LDS image limits a CU to
 // 16 waves anyway, 5 (<= 96 VGPRs, a few spilled dwords) for small scenes, where the fifth wave buys more than the spills cost.
