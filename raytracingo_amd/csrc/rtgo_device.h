@@ -591,6 +591,10 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
         if (expo == 1.0f) {
             // diffuse lobe (every path-mode bounce): powf(x, 1) == x exactly in any sound libm
             theta = acosf(base);
+        } else if (expo == 0.5f) {
+            // specularity 1 (every cornell surface in distributed mode): pow(x, 1/2) is sqrt(x), which IS correctly rounded on
+            // the device, and the lobe is as wide as the diffuse one, so float acosf is as benign here as it is there
+            theta = acosf(sqrtf(base));
         } else {
             // glossy lobe: acos(pow(x, 1/(coef+1))) sits at the ill-conditioned end of acos (argument within 1e-4 of 1),
             // where one ulp of pow moves theta by ~1e-3 relative.  Evaluate both in f64 and round, which reproduces a
