@@ -570,7 +570,9 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
 // the f64 libm bodies need ~80 VGPRs that would otherwise be charged to every wave of the megakernel.
 __device__ __attribute__((noinline)) float glossy_theta(float base, float expo)
 {
-    const float c = (float)pow((double)base, (double)expo);
+    // x^e as exp(e * log x): each f64 call is good to ~1e-16 relative, |e log x| < 20, so the product carries ~1e-14 -- far
+    // inside the 3e-8 half-ulp of the float it is rounded to, at about half the cost of the extended-precision f64 pow
+    const float c = (float)exp((double)expo * log((double)base));
     return (float)acos((double)c);
 }
 
