@@ -493,7 +493,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     // g_fprims is a read-only kernel argument, so the records arrive by scalar loads (s_load_dwordx4) into SGPRs: no LDS
     // traffic, no VGPRs for the matrices, and the loads of the next primitives overlap the tests of the current ones.
     // It also gives every ray a closest-hit bound before it enters the tree.
-#pragma unroll 4
+#pragma unroll 2
     for (int k = n_small; k < n_prims; ++k) leaf_test(g_fprims, k, o, d, tmin, best);
 #ifdef RTGO_FAST_COUNTERS
     dbg_tests += (unsigned int)(n_prims - n_small);
