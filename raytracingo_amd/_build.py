@@ -14,7 +14,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: one IEEE rounding per operation, the same statement of the arithmetic as the oracle
 # -fno-slp-vectorize: hipcc otherwise packs neighbouring scalar f32 mul/add into v_pk_*_f32; on gfx950 those issue at half
 #   rate and cost v_mov's to pair their operands (and registers: the 5-waves variant spills with them) -- measured +18 %
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize"]
+# -amdgpu-atomic-optimizer-strategy=None: the optimizer rewrites the work queue's lane-0 atomicAdd into a wave-aggregated
+#   one whose result is redistributed (and so waited for) on the spot; that turns the prefetched pull of the NEXT strip
+#   into a 1-10 us stall per strip
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
+             "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
 
 

@@ -54,6 +54,10 @@ struct rtgo_ctx {
     // queue + counters
     unsigned int* d_queue = nullptr;
     unsigned long long* d_counters = nullptr;  // 8 x u64
+#ifdef RTGO_TIMELINE
+    unsigned long long* d_timeline = nullptr;  // diagnostic build: 8 x u64 per wave
+    unsigned int timeline_waves = 0;
+#endif
     float total_ms = 0.0f, last_ms = 0.0f;
     uint32_t launches = 0;
     std::string err;
@@ -100,50 +104,70 @@ static uint32_t owned_rows_below(uint32_t y, uint32_t band_h, uint32_t n_ranks, 
     return owned_full * band_h + ((full % n_ranks == rank) ? part : 0);
 }
 
-// Screen rectangle (in unit coordinates: columns of unit_px pixels, local rows) that can contain geometry: the 8 corners of the scene's tight bounds through
-// the pinhole camera of the raygen program (d = dx*U + dy*V + W, kernel.cu:214-220).  Conservative: padded by a pixel, and
-// the whole window whenever a corner is not in front of the eye.  Only the ORDER in which tiles are handed out depends on it.
-static void hot_rectangle(const rtgo_ctx* c, LaunchParams& p, uint32_t unit_px)
+// tuning knobs for experiments (results never depend on them)
+static unsigned int env_uint(const char* name, unsigned int dflt)
 {
-    p.hot_x0 = 0;
-    p.hot_y0 = 0;
-    p.hot_w = p.tiles_x;
-    p.hot_h = p.tiles_y;
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    const long k = std::strtol(v, nullptr, 10);
+    return k > 0 ? (unsigned int)k : dflt;
+}
+
+// Window rectangle [wx0, wx1) x [wy0, wy1) that can contain geometry: the 8 corners of the scene's tight bounds through the
+// pinhole camera of the raygen program (d = dx*U + dy*V + W, kernel.cu:214-220; a sample of pixel (x, y) has dx, dy inside
+// that pixel's square).  Conservative: padded by two pixels, and the whole window whenever a corner is not in front of the
+// eye.  The kernel traces nothing for pixels outside it (their primary rays cannot reach the bounds: they are misses).
+static void scene_screen_rect(const rtgo_ctx* c, const LaunchParams& p, uint32_t& wx0, uint32_t& wx1, uint32_t& wy0, uint32_t& wy1)
+{
+    wx0 = 0;
+    wy0 = 0;
+    wx1 = p.w;
+    wy1 = p.h;
     const double uu = (double)p.U.x * p.U.x + (double)p.U.y * p.U.y + (double)p.U.z * p.U.z;
     const double vv = (double)p.V.x * p.V.x + (double)p.V.y * p.V.y + (double)p.V.z * p.V.z;
     const double ww = (double)p.Wv.x * p.Wv.x + (double)p.Wv.y * p.Wv.y + (double)p.Wv.z * p.Wv.z;
     if (!(uu > 0 && vv > 0 && ww > 0)) return;
+    // the three axes must be orthogonal for the projection below (they are for every Camera: Camera.cpp:55-69); else: no culling
+    const double uv = (double)p.U.x * p.V.x + (double)p.U.y * p.V.y + (double)p.U.z * p.V.z;
+    const double uw = (double)p.U.x * p.Wv.x + (double)p.U.y * p.Wv.y + (double)p.U.z * p.Wv.z;
+    const double vw = (double)p.V.x * p.Wv.x + (double)p.V.y * p.Wv.y + (double)p.V.z * p.Wv.z;
+    const double tol = 1e-5;
+    if (uv * uv > tol * tol * uu * vv || uw * uw > tol * tol * uu * ww || vw * vw > tol * tol * vv * ww) return;
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     for (int k = 0; k < 8; ++k) {
         const double px = c->bounds[(k & 1) ? 3 : 0] - p.eye.x, py = c->bounds[(k & 2) ? 4 : 1] - p.eye.y, pz = c->bounds[(k & 4) ? 5 : 2] - p.eye.z;
         const double a = (px * p.U.x + py * p.U.y + pz * p.U.z) / uu, b = (px * p.V.x + py * p.V.y + pz * p.V.z) / vv;
         const double w = (px * p.Wv.x + py * p.Wv.y + pz * p.Wv.z) / ww;
-        if (!(w > 1e-6)) return;  // a corner beside or behind the eye: no useful rectangle
+        if (!(w > 1e-3)) return;  // a corner beside or behind the eye: no useful rectangle
         const double sx = (a / w + 1.0) * 0.5 * p.W, sy = (b / w + 1.0) * 0.5 * p.H;
         x0 = sx < x0 ? sx : x0;
         x1 = sx > x1 ? sx : x1;
         y0 = sy < y0 ? sy : y0;
         y1 = sy > y1 ? sy : y1;
     }
+    if (!(x0 <= x1 && y0 <= y1)) return;   // NaN bounds
     // to window pixels, padded, clamped
     auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
-    const uint32_t wx0 = (uint32_t)clampd(x0 - 2.0 - p.x0, 0.0, p.w), wx1 = (uint32_t)clampd(x1 + 3.0 - p.x0, 0.0, p.w);
-    const uint32_t wy0 = (uint32_t)clampd(y0 - 2.0 - p.y0, 0.0, p.h), wy1 = (uint32_t)clampd(y1 + 3.0 - p.y0, 0.0, p.h);
-    if (wx1 <= wx0 || wy1 <= wy0) {  // the scene is off screen: every tile is cheap
-        p.hot_w = p.hot_h = 0;
-        return;
-    }
-    const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
-    p.hot_x0 = wx0 / unit_px;
-    p.hot_w = (wx1 + unit_px - 1) / unit_px - p.hot_x0;
-    p.hot_y0 = lr0;
-    p.hot_h = lr1 - lr0;
-    if (p.hot_x0 + p.hot_w > p.tiles_x) p.hot_w = p.tiles_x - p.hot_x0;
-    if (p.hot_y0 + p.hot_h > p.tiles_y) p.hot_h = p.tiles_y - p.hot_y0;
-    if (p.hot_w == 0 || p.hot_h == 0) p.hot_w = p.hot_h = 0;
+    wx0 = (uint32_t)clampd(x0 - 2.0 - p.x0, 0.0, p.w);
+    wx1 = (uint32_t)clampd(x1 + 3.0 - p.x0, 0.0, p.w);
+    wy0 = (uint32_t)clampd(y0 - 2.0 - p.y0, 0.0, p.h);
+    wy1 = (uint32_t)clampd(y1 + 3.0 - p.y0, 0.0, p.h);
+    if (wx1 <= wx0 || wy1 <= wy0) wx0 = wx1 = wy0 = wy1 = 0;   // the scene is off screen
 }
 
 extern "C" {
+
+#ifdef RTGO_TIMELINE
+// diagnostic build only (tools/timeline.py): per-wave records of the last launch; returns the number of waves
+extern "C" int rtgo_debug_timeline(rtgo_ctx* c, void* host, size_t bytes)
+{
+    if (!c || !c->d_timeline) return -1;
+    if (rtgo_sync(c)) return -1;
+    const size_t n = (size_t)c->timeline_waves * 128;
+    if (hipMemcpy(host, c->d_timeline, n < bytes ? n : bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int)c->timeline_waves;
+}
+#endif
 
 uint32_t rtgo_abi_version(void) { return RTGO_ABI_VERSION; }
 
@@ -185,7 +209,7 @@ int rtgo_create(int device, rtgo_ctx** out)
         err = hipEventCreate(&c->ev_start[i]);
         if (err == hipSuccess) err = hipEventCreate(&c->ev_stop[i]);
     }
-    if (err == hipSuccess) err = hipMalloc(&c->d_queue, kQueues * 16 * sizeof(unsigned int));
+    if (err == hipSuccess) err = hipMalloc(&c->d_queue, kQueues * kQueueStride * sizeof(unsigned int));
     if (err == hipSuccess) err = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&c->d_lights, kMaxLights * sizeof(LightRec));
@@ -390,30 +414,68 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (p.rank >= p.n_ranks) return fail(c, RTGO_E_INVALID, "rtgo_launch: rank >= n_ranks");
     p.local_rows = rtgo_local_rows(p.h, p.band_h, p.n_ranks, p.rank);
     if ((size_t)p.local_rows * p.w > c->pixels) return fail(c, RTGO_E_INVALID, "rtgo_launch: output buffer too small for this window");
+    p.eye = c->eye;
+    p.U = c->U;
+    p.V = c->V;
+    p.Wv = c->W;
+    p.bg = c->bg;
+    const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
     // scheduling: units of 64 paths = the N*N samples of `unit_px` neighbouring pixels of one row; the queue hands out STRIPS of
-    // `grab` units side by side (<= 64 pixels).  Strips are long when there is plenty of work (their pixel seeds are hashed once
-    // per strip) and short when units are scarce (small windows, one GPU's share of a tiled frame), so that every resident
-    // wave still gets >= ~8 turns.  The final grab is set below, once the grid is known.
+    // `grab` units side by side (<= 64 pixels) from the rectangle that can contain geometry.  Strips are long when there is
+    // plenty of work (their pixel seeds are hashed once per strip) and short when units are scarce (small windows, one GPU's
+    // share of a tiled frame), so that every resident wave still gets >= ~32 turns
+    // (the last strips in flight set the tail of the launch: cornell 1080p spp 16 runs 6 % faster on 1-unit strips than on 4-unit ones).
     const uint32_t nn = (uint32_t)f->sqrt_spp * (uint32_t)f->sqrt_spp;
     const uint32_t unit_px = 64u / (nn < (uint32_t)kSamplesPerPass ? nn : (uint32_t)kSamplesPerPass);
-    const uint64_t units_total = (uint64_t)((p.w + unit_px - 1) / unit_px) * p.local_rows;
+    {
+        // the same float additions, in the same order, as the kernel's in-order sum over samples that all miss (kernel.cu:232-237)
+        volatile float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+        for (uint32_t k = 0; k < nn; ++k) {
+            sx = sx + c->bg.x;
+            sy = sy + c->bg.y;
+            sz = sz + c->bg.z;
+        }
+        const float inv = 1.0f / (float)nn;
+        p.bg_pixel = v3{sx * inv, sy * inv, sz * inv};
+    }
+    uint32_t wx0 = 0, wx1 = p.w, wy0 = 0, wy1 = p.h;
+    if (!stats) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);   // the instrumented kernel traces every pixel
+    const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
+    const uint64_t units_hot = (uint64_t)((wx1 - wx0 + unit_px - 1) / unit_px) * (lr1 - lr0);
     {
         const uint64_t waves_guess = (uint64_t)c->num_cus * 16u;
-        uint32_t grab = (uint32_t)(units_total / (waves_guess * 8u));
-        const uint32_t grab_max = (64u / unit_px) < (uint32_t)kUnitsPerGrab ? (64u / unit_px) : (uint32_t)kUnitsPerGrab;
+        uint32_t grab = (uint32_t)(units_hot / (waves_guess * 32u));
+        const uint32_t grab_cap = env_uint("RTGO_GRAB_MAX", (uint32_t)kUnitsPerGrab);
+        const uint32_t grab_max = (64u / unit_px) < grab_cap ? (64u / unit_px) : grab_cap;
         grab = grab < 1u ? 1u : (grab > grab_max ? grab_max : grab);
         p.grab = grab;
     }
     const uint32_t strip_px = unit_px * p.grab;
-    p.tiles_x = (p.w + strip_px - 1) / strip_px;
-    p.tiles_y = p.local_rows;
-    if ((uint64_t)p.tiles_x * p.tiles_y > 0xFFFFFF00ull) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: window too large");
-    p.n_tiles = p.tiles_x * p.tiles_y;
+    p.hot_x0 = wx0 / strip_px;
+    p.hot_w = (wx1 + strip_px - 1) / strip_px - p.hot_x0;
+    p.hot_y0 = lr0;
+    p.hot_h = lr1 - lr0;
+    if (p.hot_w == 0 || p.hot_h == 0) p.hot_x0 = p.hot_y0 = p.hot_w = p.hot_h = 0;
+    if ((uint64_t)p.hot_w * p.hot_h > 0x7FFFFF00ull) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: window too large");
+    p.n_hot = p.hot_w * p.hot_h;
+    p.cold_x0 = p.hot_x0 * strip_px;
+    p.cold_x1 = (p.hot_x0 + p.hot_w) * strip_px < p.w ? (p.hot_x0 + p.hot_w) * strip_px : p.w;
+    p.rows_above = p.local_rows - p.hot_y0 - p.hot_h;
+    p.segs_full = (p.w + 63u) / 64u;
+    p.segs_l = p.n_hot ? (p.cold_x0 + 63u) / 64u : 0u;
+    p.segs_r = p.n_hot ? (p.w - p.cold_x1 + 63u) / 64u : 0u;
+    const uint64_t cold_segs = (uint64_t)(p.hot_y0 + p.rows_above) * p.segs_full + (uint64_t)p.hot_h * (p.segs_l + p.segs_r);
+    if (cold_segs > 0x7FFFFF00ull) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: window too large");
+    p.n_cold_segs = (uint32_t)cold_segs;
+    // cold chunks: about two per resident wave
+    p.cold_cs = (uint32_t)((cold_segs + (uint64_t)c->num_cus * 32u - 1) / ((uint64_t)c->num_cus * 32u));
+    if (p.cold_cs == 0) p.cold_cs = 1;
+    const uint32_t n_cold = (p.n_cold_segs + p.cold_cs - 1) / p.cold_cs;
+    p.n_tiles = p.n_hot + n_cold;
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
     p.fnodes = c->d_fnodes;
     p.fprims = c->d_fprims;
-    const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
     p.n_small = c->n_small;
     p.stack_depth = stats ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
     p.lights = c->d_lights;
@@ -421,6 +483,10 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.image = c->d_image;
     p.queue = c->d_queue;
     p.counters = c->d_counters;
+#ifdef RTGO_TIMELINE
+    if (!c->d_timeline) RTGO_HIP(c, hipMalloc(&c->d_timeline, 16384 * 128));
+    p.timeline = c->d_timeline;
+#endif
     p.n_prims = (int)c->n_prims;
     p.n_nodes = 2 * (int)c->n_prims - 1;
     p.n_lights = c->n_lights;
@@ -428,12 +494,6 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.max_depth = f->max_trace_depth;
     p.frame = f->frame_count;
     p.ambient = f->use_ambient ? 1 : 0;
-    p.eye = c->eye;
-    p.U = c->U;
-    p.V = c->V;
-    p.Wv = c->W;
-    p.bg = c->bg;
-    hot_rectangle(c, p, strip_px);
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
@@ -464,8 +524,15 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const unsigned int need = (p.n_tiles + (block / 64) - 1) / (block / 64);
     if (grid > need) grid = need;
 
+    if (std::getenv("RTGO_DEBUG"))
+        std::fprintf(stderr, "rtgo_launch: grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d\n",
+                     grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth);
+#ifdef RTGO_TIMELINE
+    c->timeline_waves = grid * (unsigned int)(block / 64);
+    if (c->timeline_waves > 16384) return fail(c, RTGO_E_UNSUPPORTED, "timeline buffer too small");
+#endif
     RTGO_HIP(c, hipSetDevice(c->device));
-    RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, kQueues * 16 * sizeof(unsigned int), c->stream));
+    RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned int), c->stream));
     if (c->ev_pending == rtgo_ctx::kEvRing) {
         int rc = harvest_events(c, 1);
         if (rc) return rc;

@@ -19,7 +19,8 @@ constexpr int kDefaultLeafBudget = 6;   // fast walk: LBVH subtrees whose leaf-t
 constexpr int kMaxPrims = 512;
 constexpr int kMaxLights = 10;
 constexpr int kSamplesPerPass = 16;   // samples of one pixel that run side by side (the in-order sum costs this many lane exchanges)
-constexpr int kQueues = 8;           // work-queue heads (one per XCD label)
+constexpr int kQueues = 32;          // work-queue heads (power of two <= 64; 8 / 16 / 32 heads: a 1/8 frame share takes 0.261 / 0.248 / 0.244 ms)
+constexpr unsigned int kQueueStride = 16;   // words between two heads: one 64-byte line each
 constexpr int kUnitsPerGrab = 4;     // most units (64 paths each) in one strip = one queue entry (longer strips: seeds cheaper, balance worse)
 constexpr int kMaxLevels = 5;        // bounce records kept per path (maxTraceDepth <= 5)
 constexpr float kPi = 3.14159265358979323846f;  // M_PIf, sutil/vec_math.h:43
@@ -57,11 +58,25 @@ struct LaunchParams {
     int ambient;
     unsigned int x0, y0, w, h;      // window
     unsigned int band_h, n_ranks, rank, local_rows;
-    unsigned int tiles_x, n_tiles;   // strips per local row, strips in this launch
-    // strips inside this rectangle (strip column, local row) are handed out first: see tile_of()
-    unsigned int hot_x0, hot_y0, hot_w, hot_h, tiles_y;
+    unsigned int n_tiles;            // work-queue entries of this launch = n_hot strips, then n_cold chunks
+    // The strips that can contain geometry form a rectangle of hot_w x hot_h strips at (strip column hot_x0, local row hot_y0):
+    // the screen bounds of the scene, computed by the host.  Queue entries [0, n_hot) are those strips, row-major.
+    unsigned int hot_x0, hot_y0, hot_w, hot_h, n_hot;
+    // Every pixel outside it is background whatever its samples' jitter (no primary ray can reach the scene's bounds), so the
+    // timed kernel writes those without tracing (the instrumented kernel, which defines V/T/h, traces everything: the host
+    // then makes the rectangle the whole window).  They are cut into 64-pixel row segments, enumerated region by region
+    // (rows below the rectangle, rows above, left of it, right of it); queue entry n_hot + c is cold chunk c = segments
+    // [c*cold_cs, (c+1)*cold_cs).  They sit at the END of the queue: cheap filler for the waves that run out of strips first.
+    unsigned int cold_x0, cold_x1;   // window columns [cold_x0, cold_x1) belong to the rectangle's strips
+    unsigned int rows_above;         // local rows over the rectangle (those below it: hot_y0)
+    unsigned int segs_full, segs_l, segs_r;   // 64-pixel segments per full row, per row left / right of the rectangle
+    unsigned int n_cold_segs, cold_cs;
     unsigned int grab;               // units per strip (1..kUnitsPerGrab, strip <= 64 pixels)
+#ifdef RTGO_TIMELINE
+    unsigned long long* timeline;    // diagnostic build: 8 words per wave, see tools/timeline.py
+#endif
     v3 eye, U, V, Wv, bg;
+    v3 bg_pixel;                     // ((0 + bg) + bg + ... N*N times) * (1/(N*N)) in float: the value of a pixel whose samples all miss
 };
 
 // ---- float3 helpers, same operation order as sutil/vec_math.h ----------------------------------------------------
@@ -621,43 +636,55 @@ __device__ __forceinline__ unsigned int wave_sum(unsigned int v)
     return v;
 }
 
-// Queue index -> strip (column, local row).  The strips that can contain geometry (the screen rectangle of the scene's bounds,
-// computed by the host) come first, the empty ones last: an in-scene strip costs ~10x an empty one, so handing them out in
-// raster order leaves waves idle behind the last expensive strips; with the cheap ones at the end of the queue they fill
-// that tail instead.
-__device__ __forceinline__ void tile_of(const LaunchParams& p, unsigned int idx, unsigned int& tx, unsigned int& ty)
+// running average + 8-bit image of one pixel: kernel.cu:236-246
+__device__ __forceinline__ void write_pixel(const LaunchParams& p, size_t idx, v3 cur)
 {
-    const unsigned int hot = p.hot_w * p.hot_h;
-    if (idx < hot) {
-        tx = p.hot_x0 + idx % p.hot_w;
-        ty = p.hot_y0 + idx / p.hot_w;
-        return;
+    if (p.frame > 0) {
+        const float4 prev4 = p.accum[idx];
+        const v3 prev = mk(prev4.x, prev4.y, prev4.z);
+        const float ratio = 1.0f / (float)(p.frame + 1);
+        cur = vadd(prev, vscale(vsub(cur, prev), ratio));  // lerp, vec_math.h:496-499
     }
-    unsigned int j = idx - hot;
-    const unsigned int below = p.hot_y0 * p.tiles_x;                              // full rows under the rectangle
+    p.accum[idx] = make_float4(cur.x, cur.y, cur.z, 1.0f);
+    // make_color, kernel.cu:90-98
+    p.image[idx] = make_uchar4((unsigned char)(clampf(cur.x, 0.0f, 1.0f) * 255.0f), (unsigned char)(clampf(cur.y, 0.0f, 1.0f) * 255.0f),
+                               (unsigned char)(clampf(cur.z, 0.0f, 1.0f) * 255.0f), 255u);
+}
+
+// Cold segment s -> (local row, first window column, column limit); see LaunchParams.  Wave-uniform.
+__device__ __forceinline__ void cold_segment(const LaunchParams& p, unsigned int s, unsigned int& lr, unsigned int& x, unsigned int& lim)
+{
+    unsigned int j = s;
+    const unsigned int below = p.hot_y0 * p.segs_full;
     if (j < below) {
-        tx = j % p.tiles_x;
-        ty = j / p.tiles_x;
+        lr = j / p.segs_full;
+        x = (j - lr * p.segs_full) * 64u;
+        lim = p.w;
         return;
     }
     j -= below;
-    const unsigned int above = (p.tiles_y - p.hot_y0 - p.hot_h) * p.tiles_x;      // full rows over it
+    const unsigned int above = p.rows_above * p.segs_full;
     if (j < above) {
-        tx = j % p.tiles_x;
-        ty = p.hot_y0 + p.hot_h + j / p.tiles_x;
+        const unsigned int r = j / p.segs_full;
+        lr = p.hot_y0 + p.hot_h + r;
+        x = (j - r * p.segs_full) * 64u;
+        lim = p.w;
         return;
     }
     j -= above;
-    const unsigned int left = p.hot_h * p.hot_x0;                                 // strip on its left
+    const unsigned int left = p.hot_h * p.segs_l;
     if (j < left) {
-        tx = j % p.hot_x0;
-        ty = p.hot_y0 + j / p.hot_x0;
+        const unsigned int r = j / p.segs_l;
+        lr = p.hot_y0 + r;
+        x = (j - r * p.segs_l) * 64u;
+        lim = p.cold_x0;
         return;
     }
     j -= left;
-    const unsigned int dw = p.tiles_x - p.hot_x0 - p.hot_w;                       // strip on its right
-    tx = p.hot_x0 + p.hot_w + j % dw;
-    ty = p.hot_y0 + j / dw;
+    const unsigned int r = j / p.segs_r;
+    lr = p.hot_y0 + r;
+    x = p.cold_x1 + (j - r * p.segs_r) * 64u;
+    lim = p.w;
 }
 
 // =====================================================================================================================
@@ -693,6 +720,13 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     float* s_lv = reinterpret_cast<float*>(s_lights + kMaxLights) + threadIdx.x;
 
     const int tid = threadIdx.x;
+#ifdef RTGO_TIMELINE
+    const unsigned long long tl_t0 = wall_clock64();
+    unsigned long long tl_t1 = 0, tl_first = 0, tl_lanes = 0, tl_qwait = 0, tl_cold = 0;
+    unsigned int tl_hot = 0;
+    unsigned long long tl_a = 0, tl_b = 0, tl_c = 0, tl_d = 0;
+    unsigned int tl_units = 0, tl_iters = 0;
+#endif
     if (STATS) {
         for (int i = tid; i < 2 * p.n_nodes; i += kBlock) s_nodes[i] = p.nodes[i];
         for (int i = tid; i < 6 * p.n_prims; i += kBlock) s_prims[i] = p.prims[i];
@@ -708,6 +742,9 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     }
     __syncthreads();
 
+#ifdef RTGO_TIMELINE
+    tl_t1 = wall_clock64();
+#endif
     float2* s_stack = s_stack_base + tid;
     const int lane = tid & 63;
     const unsigned int nn = (unsigned int)(p.sqrt_spp * p.sqrt_spp);
@@ -729,38 +766,71 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 
     unsigned int c_rays = 0, c_occl = 0, c_nodes = 0, c_tests = 0, c_hits = 0;
 
-    // Work queue: kQueues heads, 64 bytes apart; head q serves the units u with u % kQueues == q.  A wave pulls from the head
-    // of its workgroup's label (blockIdx % 8: workgroups b and b+8 share an XCD) and, when that runs dry, from the others.
-    // One head saturates at ~88 dequeues/us chip-wide (MI355X_MICROARCH "dequeue"), which a frame of 64-path units reaches;
-    // eight heads on different lines do not.  Results do not depend on who takes what.
+    // Work queue: kQueues heads, 64 bytes apart; head q serves the entries u with u % kQueues == q.  A wave pulls from the head
+    // blockIdx % kQueues and, when that runs dry, from the others.  One head saturates at ~88 dequeues/us chip-wide
+    // (MI355X_MICROARCH "dequeue"), which 5120 waves on 64-path units exceed several times over; heads on different lines
+    // proceed side by side.  Results do not depend on who takes what.
     unsigned int q = blockIdx.x % (unsigned int)kQueues;
-    // the pull for the NEXT grab is issued before the current one is processed, so its ~1-2 us round trip hides behind work
-    unsigned int pending = 0;
-    if (lane == 0) pending = atomicAdd(p.queue + 16u * q, 1u);
+    // The FIRST strip of every wave is assigned statically (its rank among the waves of its queue): 5120 waves pulling at once
+    // would queue up behind the heads for 10-30 us.  Head q therefore counts from n_static(q) = the waves on queue q.
+    const unsigned int wpb = (unsigned int)kBlock >> 6;
+    auto n_static = [&](unsigned int qq) { return ((gridDim.x + (unsigned int)kQueues - 1u - qq) / (unsigned int)kQueues) * wpb; };
+    // the pull for the NEXT strip is issued before the current one is processed, so its ~1-2 us round trip hides behind work
+    // (the head's offset is added when the value is USED: arithmetic on it here would make the wave wait for the atomic at once)
+    unsigned int pending = (blockIdx.x / (unsigned int)kQueues) * wpb + ((unsigned int)tid >> 6), pending_off = 0u;
     for (;;) {
         const unsigned int q_count = (p.n_tiles + (unsigned int)kQueues - 1u - q) / (unsigned int)kQueues;   // units in queue q
-        const unsigned int first = __builtin_amdgcn_readfirstlane(pending);
+#ifdef RTGO_TIMELINE
+        const unsigned long long tl_q0 = wall_clock64();
+#endif
+        const unsigned int first = __builtin_amdgcn_readfirstlane(pending) + pending_off;
+#ifdef RTGO_TIMELINE
+        tl_qwait += wall_clock64() - tl_q0;
+        if (tl_a == 0) tl_a = wall_clock64();
+#endif
         if (first >= q_count) {
             // own head is past its end: look at all heads at once (one load, lanes 0..7) and move to one that still has work.
             // Heads only grow, so "none has work" is final: the wave leaves and the grid drains.
             unsigned int head = 0xFFFFFFFFu, cnt_l = 0u;
             if (lane < kQueues) {
-                head = __hip_atomic_load(p.queue + 16u * (unsigned int)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                head = __hip_atomic_load(p.queue + kQueueStride * (unsigned int)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_static((unsigned int)lane);
                 cnt_l = (p.n_tiles + (unsigned int)kQueues - 1u - (unsigned int)lane) / (unsigned int)kQueues;
             }
             const unsigned long long open = __ballot(head < cnt_l);
             if (open == 0ull) break;
             q = (unsigned int)(__ffsll((long long)open) - 1);
-            if (lane == 0) pending = atomicAdd(p.queue + 16u * q, 1u);
+            // (rare path: consume the result at once, so that no write to its register is pending where the paths join --
+            // the compiler would otherwise wait for the common path's prefetch there as well)
+            unsigned int stolen = 0;
+            if (lane == 0) stolen = atomicAdd(p.queue + kQueueStride * q, 1u);
+            pending = __builtin_amdgcn_readfirstlane(stolen);
+            pending_off = n_static(q);
             continue;
         }
-        if (lane == 0) pending = atomicAdd(p.queue + 16u * q, 1u);
+        if (lane == 0) pending = atomicAdd(p.queue + kQueueStride * q, 1u);
+        pending_off = n_static(q);
         // one queue entry = one STRIP: p.grab units side by side on a row (at most 64 pixels).  The strip's tea<16> pixel seeds
         // are computed once, one pixel per lane (the hash is 16 dependent rounds: ~160 instructions whether 4 or 64 lanes need
         // it), and handed to the units by lane exchange.
         const unsigned int strip = first * (unsigned int)kQueues + q;
-        unsigned int sx, lr;   // strip column, local (compact) row
-        tile_of(p, strip, sx, lr);
+        if (strip >= p.n_hot) {
+            // cold chunk: pixels no primary ray of which can reach the scene's bounds.  Each of their N*N samples is one ray that
+            // misses (__miss__ms, kernel.cu:419-423), so the pixel is the in-order sum of N*N background colours / (N*N): p.bg_pixel.
+            const unsigned int s0 = (strip - p.n_hot) * p.cold_cs;
+            const unsigned int s1 = s0 + p.cold_cs < p.n_cold_segs ? s0 + p.cold_cs : p.n_cold_segs;
+            for (unsigned int s = s0; s < s1; ++s) {
+                unsigned int clr, cx, clim;
+                cold_segment(p, s, clr, cx, clim);
+                const unsigned int lx = cx + (unsigned int)lane;
+                if (lx < clim) {
+                    write_pixel(p, (size_t)clr * p.w + lx, p.bg_pixel);
+                    c_rays += nn;
+                }
+            }
+            continue;
+        }
+        const unsigned int lr = p.hot_y0 + strip / p.hot_w;   // local (compact) row
+        const unsigned int sx = p.hot_x0 + (strip - (lr - p.hot_y0) * p.hot_w);   // strip column
         // local row -> window row under the band interleave
         const unsigned int band = lr / p.band_h;
         const unsigned int wrow = (band * p.n_ranks + p.rank) * p.band_h + (lr - band * p.band_h);
@@ -768,6 +838,9 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         const float fy = (float)gy;
         const unsigned int strip_x0 = sx * p.grab * P;
         const unsigned int strip_seed = tea16(p.W * gy + (p.x0 + strip_x0 + (unsigned int)lane), p.frame);
+#ifdef RTGO_TIMELINE
+        if (tl_b == 0) tl_b = wall_clock64() + (strip_seed == 0x12345u ? 1 : 0);
+#endif
 #pragma unroll 1
         for (unsigned int ui = 0; ui < p.grab; ++ui) {
         const unsigned int lx = strip_x0 + ui * P + pl;
@@ -811,7 +884,19 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         int sPrim = 0, sLight = 0;
         bool sNVneg = false;
 
+#ifdef RTGO_TIMELINE
+        if (tl_units++ == 0) tl_first = wall_clock64();
+        if (ui == 0) {
+            if (strip < p.n_hot) tl_hot += 1;
+            else if (tl_cold == 0) tl_cold = wall_clock64();
+        }
+#endif
         while (__ballot(active) != 0ull) {
+#ifdef RTGO_TIMELINE
+            if (tl_iters == 1 && tl_c == 0) tl_c = wall_clock64();
+            tl_iters += 1;
+            tl_lanes += (unsigned long long)__popcll(__ballot(active));
+#endif
             if (active) {
                 Hit h;
                 c_rays += 1;
@@ -1009,23 +1094,22 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 
         if (in_range && kl == 0) {
             // kernel.cu:236-246.  float3 / float multiplies by the reciprocal (vec_math.h:479-483)
-            v3 cur = vscale(color, 1.0f / (float)nn);
-            const size_t idx = (size_t)lr * p.w + lx;
-            if (p.frame > 0) {
-                const float4 prev4 = p.accum[idx];
-                const v3 prev = mk(prev4.x, prev4.y, prev4.z);
-                const float ratio = 1.0f / (float)(p.frame + 1);
-                cur = vadd(prev, vscale(vsub(cur, prev), ratio));  // lerp, vec_math.h:496-499
-            }
-            p.accum[idx] = make_float4(cur.x, cur.y, cur.z, 1.0f);
-            // make_color, kernel.cu:90-98
-            p.image[idx] = make_uchar4((unsigned char)(clampf(cur.x, 0.0f, 1.0f) * 255.0f),
-                                       (unsigned char)(clampf(cur.y, 0.0f, 1.0f) * 255.0f),
-                                       (unsigned char)(clampf(cur.z, 0.0f, 1.0f) * 255.0f), 255u);
+            write_pixel(p, (size_t)lr * p.w + lx, vscale(color, 1.0f / (float)nn));
         }
+#ifdef RTGO_TIMELINE
+        if (tl_d == 0) tl_d = wall_clock64();
+#endif
         }  // unit
     }
 
+#ifdef RTGO_TIMELINE
+    if (lane == 0) {
+        unsigned long long* r = p.timeline + 16ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        r[8] = tl_a; r[9] = tl_b; r[10] = tl_c; r[11] = tl_d;
+        r[0] = tl_t0; r[1] = tl_t1; r[2] = tl_first; r[3] = wall_clock64(); r[4] = tl_units | ((unsigned long long)tl_hot << 32); r[5] = tl_iters; r[6] = tl_lanes;
+        r[7] = tl_qwait | ((tl_cold ? tl_cold - tl_t0 : 0ull) << 32);
+    }
+#endif
     // one atomic per wave per counter
     c_rays = wave_sum(c_rays);
     c_occl = wave_sum(c_occl);

@@ -442,3 +442,52 @@ def test_odd_sample_counts_and_tiny_images(capi, oracle):
         assert_parity(acc, racc, img, rimg, min_frac=0.97 if W * H < 100 else 0.99, what="%dx%d N=%d" % (W, H, n))
         assert ctx.stats()["rays_total"] == rc["rays_total"] or abs(ctx.stats()["rays_total"] - rc["rays_total"]) <= 0.01 * rc["rays_total"]
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "plateau", "mirror_spheres", "slide"])
+def test_background_culling_random_cameras(capi, oracle, name):
+    """The timed kernel traces nothing for pixels outside the screen rectangle of the scene's bounds (their primary rays are
+    misses by construction) while the instrumented kernel traces every pixel: both must give the same frame bit for bit, and
+    the same ray count, wherever the camera stands -- scene small in view, partly off screen, behind the eye, sheared axes --
+    and for windows and band shares that cut the rectangle."""
+    W, H, n = 144, 80, 2
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    bb = np.asarray(t["aabb"], dtype=np.float64).reshape(-1, 6)
+    lo, hi = bb[:, :3].min(axis=0), bb[:, 3:].max(axis=0)
+    centre, size = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+    rng = np.random.default_rng(hash(name) % 1000)
+    prev = rng.random((H, W, 4), dtype=np.float32)
+    culled = 0
+    for trial in range(14):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        eye = oracle.f32(centre + d * size * rng.uniform(0.8, 6.0))
+        look = oracle.f32(centre + rng.normal(size=3) * size * rng.choice([0.05, 0.4, 1.5]))
+        up = oracle.f32([rng.uniform(-0.3, 0.3), 1.0, rng.uniform(-0.3, 0.3)])
+        U, V, Wv = [np.zeros(3, dtype=np.float32) for _ in range(3)]
+        oracle.lib().oracle_camera_uvw(oracle.fptr(eye), oracle.fptr(look), oracle.fptr(up), float(rng.uniform(15.0, 100.0)),
+                                       np.float32(np.float32(W) / np.float32(H)), oracle.fptr(U), oracle.fptr(V), oracle.fptr(Wv))
+        if trial == 12:
+            U = (U + np.float32(0.2) * V).astype(np.float32)     # sheared axes: the rectangle cannot be trusted, nothing is culled
+        if trial == 13:
+            eye = oracle.f32(centre)                              # eye inside the bounds
+        ctx.set_camera(eye, U, V, Wv)
+        for (window, bands) in [(None, (4, 1, 0)), ((30, 10, 75, 50), (4, 1, 0)), (None, (4, 3, 2))]:
+            if trial % 3 and window is not None:
+                continue
+            x0, y0, w, h = window if window else (0, 0, W, H)
+            rows = [r for r in range(h) if (r // bands[0]) % bands[1] == bands[2]]
+            pv = np.ascontiguousarray(prev[y0:y0 + h, x0:x0 + w][rows])
+            ctx.reset_stats()
+            fast, fimg = gpu_render(capi, ctx, W, H, n, 3, True, window=window, bands=bands, prev=pv)
+            rays_fast = ctx.stats()["rays_total"]
+            ctx.reset_stats()
+            canon, cimg = gpu_render(capi, ctx, W, H, n, 3, True, window=window, bands=bands, stats=True, prev=pv)
+            st = ctx.stats()
+            assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), (name, trial, window, bands)
+            assert np.array_equal(fimg, cimg)
+            assert rays_fast == st["rays_total"], (name, trial, rays_fast, st["rays_total"])
+            culled += int(st["hits"] == 0 or st["rays_total"] < 2 * n * n * len(rows) * w)
+    ctx.close()
+    print(name, "launches dominated by background:", culled)
