@@ -218,14 +218,14 @@ def main():
     dt = time.perf_counter() - t0
     st = ctx.stats()
     tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
-    rr = torch.tensor([float(st["rays_total"])], dtype=torch.float64, device=rdev)
+    rr = torch.tensor([float(st["rays_total"]), float(st["rays_culled"])], dtype=torch.float64, device=rdev)
     km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1)], dtype=torch.float64, device=rdev)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
-    rays_total = float(rr.item())
+    rays_total, rays_culled = [float(x) for x in rr.tolist()]
     kernel_ms = float(km.item())          # slowest rank's average megakernel duration (HIP events on the launch stream)
 
     if rank == 0:
@@ -244,7 +244,11 @@ def main():
                                    (args.scene, W, H, args.mode, N, N * N, args.warmup, args.warmup + args.steps - 1),
                        "primitives": int(len(t["type"])), "tiling": "4-row bands interleaved over %d GPU(s)" % world,
                        "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (world > 1 and not args.no_gather) else "none",
-                       "rays_per_frame": int(round(rays_per_launch))},
+                       "rays_per_frame": int(round(rays_per_launch)),
+                       # primary rays of pixels outside the screen rectangle of the scene's bounds: counted (the reference traces
+                       # them, they miss) but answered by that rectangle instead of a traversal; the rate without them is given too
+                       "rays_culled_per_frame": int(round(rays_culled / args.steps)),
+                       "mrays_traversed_only": round((rays_total - rays_culled) / dt / 1e6, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": (round(traffic[0]) if traffic and world == 1 else None),

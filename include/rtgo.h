@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTGO_ABI_VERSION 1
+#define RTGO_ABI_VERSION 2
 #define RTGO_MAX_PRIMS 512  /* scene staged whole in LDS (largest reference scene: checkered, 390) */
 #define RTGO_MAX_LIGHTS 10  /* Params::MAX_LIGHTS, engine/params.h:115 */
 
@@ -98,6 +98,8 @@ typedef struct rtgo_stats {
     uint32_t lbvh_depth;      /* depth of the on-device LBVH */
     uint64_t dbg_fast_boxes;  /* diagnostic builds (-DRTGO_FAST_COUNTERS) only: boxes tested by the fast walk, else 0 */
     uint64_t dbg_fast_tests;  /* diagnostic builds only: leaf tests of the fast walk incl. the up-front list, else 0 */
+    uint64_t rays_culled;     /* primary rays among rays_total that were answered (as misses) by the screen rectangle of the
+                                 scene's bounds instead of a traversal; always 0 for collect_stats launches */
 } rtgo_stats;
 
 typedef struct rtgo_ctx rtgo_ctx;

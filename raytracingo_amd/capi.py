@@ -56,7 +56,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("rays_occlusion", C.c_uint64), ("node_visits", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("last_launch_ms", C.c_float),
                 ("total_launch_ms", C.c_float), ("launches", C.c_uint32), ("lbvh_depth", C.c_uint32),
-                ("dbg_fast_boxes", C.c_uint64), ("dbg_fast_tests", C.c_uint64)]
+                ("dbg_fast_boxes", C.c_uint64), ("dbg_fast_tests", C.c_uint64), ("rays_culled", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

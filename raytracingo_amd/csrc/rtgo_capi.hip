@@ -52,7 +52,9 @@ struct rtgo_ctx {
     size_t pixels = 0;
     bool own_output = false;
     // queue + counters
-    unsigned int* d_queue = nullptr;
+    unsigned int* d_queue = nullptr;          // two sets of work-queue heads: a launch counts on one and zeroes the other for the next
+    int queue_set = 0;
+    unsigned long long rays_culled = 0;       // since rtgo_reset_stats (host arithmetic: the cold pixels of each launch x N*N)
     unsigned long long* d_counters = nullptr;  // 8 x u64
 #ifdef RTGO_TIMELINE
     unsigned long long* d_timeline = nullptr;  // diagnostic build: 8 x u64 per wave
@@ -209,7 +211,8 @@ int rtgo_create(int device, rtgo_ctx** out)
         err = hipEventCreate(&c->ev_start[i]);
         if (err == hipSuccess) err = hipEventCreate(&c->ev_stop[i]);
     }
-    if (err == hipSuccess) err = hipMalloc(&c->d_queue, kQueues * kQueueStride * sizeof(unsigned int));
+    if (err == hipSuccess) err = hipMalloc(&c->d_queue, 2 * kQueues * kQueueStride * sizeof(unsigned int));
+    if (err == hipSuccess) err = hipMemset(c->d_queue, 0, 2 * kQueues * kQueueStride * sizeof(unsigned int));
     if (err == hipSuccess) err = hipMalloc(&c->d_counters, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMemset(c->d_counters, 0, 8 * sizeof(unsigned long long));
     if (err == hipSuccess) err = hipMalloc(&c->d_lights, kMaxLights * sizeof(LightRec));
@@ -264,6 +267,10 @@ int rtgo_destroy(rtgo_ctx* c)
 int rtgo_set_stream(rtgo_ctx* c, void* hip_stream)
 {
     if (!c) return RTGO_E_INVALID;
+    // launches are ordered by the stream they run on (accumulation buffer, the two alternating sets of queue heads): finish the
+    // work on the old stream before moving
+    const int rc = rtgo_sync(c);
+    if (rc) return rc;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return RTGO_OK;
 }
@@ -481,7 +488,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.lights = c->d_lights;
     p.accum = c->d_accum;
     p.image = c->d_image;
-    p.queue = c->d_queue;
+    p.queue = c->d_queue + (size_t)c->queue_set * kQueues * kQueueStride;
+    p.queue_next = c->d_queue + (size_t)(1 - c->queue_set) * kQueues * kQueueStride;
     p.counters = c->d_counters;
 #ifdef RTGO_TIMELINE
     if (!c->d_timeline) RTGO_HIP(c, hipMalloc(&c->d_timeline, 16384 * 128));
@@ -532,7 +540,6 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (c->timeline_waves > 16384) return fail(c, RTGO_E_UNSUPPORTED, "timeline buffer too small");
 #endif
     RTGO_HIP(c, hipSetDevice(c->device));
-    RTGO_HIP(c, hipMemsetAsync(c->d_queue, 0, kQueues * kQueueStride * sizeof(unsigned int), c->stream));
     if (c->ev_pending == rtgo_ctx::kEvRing) {
         int rc = harvest_events(c, 1);
         if (rc) return rc;
@@ -548,6 +555,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     else hipLaunchKernelGGL((render_kernel<false, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
+    c->queue_set = 1 - c->queue_set;
+    c->rays_culled += ((unsigned long long)p.local_rows * p.w - (unsigned long long)p.hot_h * (p.cold_x1 - p.cold_x0)) * nn;
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;
     c->ev_pending++;
     c->launches++;
@@ -608,6 +617,7 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     out->lbvh_depth = (uint32_t)c->lbvh_depth;
     out->dbg_fast_boxes = h[5];
     out->dbg_fast_tests = h[6];
+    out->rays_culled = c->rays_culled;
     return RTGO_OK;
 }
 
@@ -622,6 +632,7 @@ int rtgo_reset_stats(rtgo_ctx* c)
     c->total_ms = 0.0f;
     c->last_ms = 0.0f;
     c->launches = 0;
+    c->rays_culled = 0;
     return RTGO_OK;
 }
 

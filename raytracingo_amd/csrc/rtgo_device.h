@@ -49,7 +49,8 @@ struct LaunchParams {
     const LightRec* lights;
     float4* accum;
     uchar4* image;
-    unsigned int* queue;            // kQueues work-queue heads, 16 words apart (zeroed before every launch)
+    unsigned int* queue;            // kQueues work-queue heads, kQueueStride words apart, all zero when the launch starts
+    unsigned int* queue_next;       // the other set of heads: zeroed by this launch for the next one (no memset between frames)
     unsigned long long* counters;   // [0] rays_total [1] rays_occlusion [2] node_visits [3] prim_tests [4] hits
     int n_prims, n_nodes, n_lights;
     unsigned int W, H;              // full image
@@ -720,6 +721,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     float* s_lv = reinterpret_cast<float*>(s_lights + kMaxLights) + threadIdx.x;
 
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid < kQueues) p.queue_next[kQueueStride * (unsigned int)tid] = 0u;
 #ifdef RTGO_TIMELINE
     const unsigned long long tl_t0 = wall_clock64();
     unsigned long long tl_t1 = 0, tl_first = 0, tl_lanes = 0, tl_qwait = 0, tl_cold = 0;
