@@ -60,7 +60,7 @@ def cpu_baseline(scene, width, height, sample, path, seconds_cap=30.0):
     wq, hq = width // 4, height // 4
     win = ((width - wq) // 2, (height - hq) // 2, wq, hq)
     t0 = time.perf_counter()
-    _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, window=win, mode=1, threads=cores))
+    acc, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, window=win, mode=1, threads=cores))
     dt = time.perf_counter() - t0
     sample_desc = "centre crop %dx%d of frame 0" % (wq, hq)
     rate = c["rays_total"] / dt
@@ -68,13 +68,26 @@ def cpu_baseline(scene, width, height, sample, path, seconds_cap=30.0):
     full_rays_est = width * height * sample * sample * 2.3
     if full_rays_est / rate < seconds_cap * 0.6:
         t0 = time.perf_counter()
-        _, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, mode=1, threads=cores))
+        acc, _, c = O.render(sc, O.frame(width, height, sample, 0, path=path, mode=1, threads=cores))
         dt = time.perf_counter() - t0
         sample_desc = "full frame 0 (%dx%d, %d spp)" % (width, height, sample * sample)
+        win = (0, 0, width, height)
     return {"value": round(c["rays_total"] / dt / 1e6, 3), "unit": "Mray/s", "cores": cores, "kind": "port",
             "sample": sample_desc, "seconds": round(dt, 2), "rays": c["rays_total"],
             "V": round(c["node_visits"] / c["rays_total"], 3), "T": round(c["prim_tests"] / c["rays_total"], 3),
-            "h": round(c["hits"] / c["rays_total"], 4)}
+            "h": round(c["hits"] / c["rays_total"], 4)}, acc, win
+
+
+def parity_against(ref_accum, win, gpu_accum):
+    """the checker's verdict on the GPU's frame 0 over the window the CPU baseline rendered (tolerance of tests/parity.py)"""
+    import numpy as np
+    x0, y0, w, h = win
+    g = gpu_accum[y0:y0 + h, x0:x0 + w, :3].astype(np.float64)
+    r = np.asarray(ref_accum)[..., :3].astype(np.float64)
+    ok = (np.abs(g - r) <= 1e-4 * np.maximum(1.0, np.abs(r))).all(axis=-1)
+    return {"window": list(win), "pixels": int(ok.size), "frac_within_1e-4": round(float(ok.mean()), 6),
+            "frac_bit_exact": round(float((gpu_accum[y0:y0 + h, x0:x0 + w, :3] == np.asarray(ref_accum)[..., :3]).all(axis=-1).mean()), 6),
+            "mean_rel_diff": float(abs(g.mean() - r.mean()) / max(r.mean(), 1e-30))}
 
 
 def main():
@@ -272,7 +285,12 @@ def main():
             ctx.sync()
             out["rehearsal_frame_matches_single_gpu"] = bool(torch.equal(whole_i, full_image))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, W, H, N, path)
+            out["cpu_baseline"], ref_acc, ref_win = cpu_baseline(args.scene, W, H, N, path)
+            # the same frame 0 on the GPU (untimed, scratch buffers), held against what the oracle just rendered
+            ctx.bind_output(scratch_a.data_ptr(), scratch_i.data_ptr(), rows_pad * W)
+            ctx.launch(capi.make_frame(W, H, N, 0, path, False, None, (band_h, 1, 0)))
+            ctx.sync()
+            out["cpu_baseline"]["gpu_frame0_vs_oracle"] = parity_against(ref_acc, ref_win, scratch_a[:H].cpu().numpy())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

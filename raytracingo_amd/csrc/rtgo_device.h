@@ -495,8 +495,15 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
                                                  const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int bshift,
                                                  int n_small, int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out,
-                                                 unsigned int& dbg_boxes, unsigned int& dbg_tests)
+                                                 unsigned int& dbg_boxes, unsigned int& dbg_tests
+#ifdef RTGO_TIMELINE
+                                                 , unsigned long long& tl_big, unsigned long long& tl_tree
+#endif
+)
 {
+#ifdef RTGO_TIMELINE
+    const unsigned long long tl_s0 = wall_clock64();
+#endif
     FastHit best;
     best.t = tmax;
     best.nobj = mk(0.0f, 0.0f, 0.0f);
@@ -513,6 +520,10 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     for (int k = n_small; k < n_prims; ++k) leaf_test(g_fprims, k, o, d, tmin, best);
 #ifdef RTGO_FAST_COUNTERS
     dbg_tests += (unsigned int)(n_prims - n_small);
+#endif
+#ifdef RTGO_TIMELINE
+    const unsigned long long tl_s1 = wall_clock64() + (best.pos == 12345 ? 1 : 0);
+    tl_big += tl_s1 - tl_s0;
 #endif
     const v3 id = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
@@ -574,6 +585,9 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
             have = pop();
         }
     }
+#ifdef RTGO_TIMELINE
+    tl_tree += wall_clock64() + (best.pos == 12345 ? 1 : 0) - tl_s1;
+#endif
     if (best.pos < 0) return false;
     const float4 r0 = s_fprims[4 * best.pos + 0], r1 = s_fprims[4 * best.pos + 1], r2 = s_fprims[4 * best.pos + 2];
     out.t = best.t;
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     const unsigned long long tl_t0 = wall_clock64();
     unsigned long long tl_t1 = 0, tl_first = 0, tl_lanes = 0, tl_qwait = 0, tl_cold = 0;
     unsigned int tl_hot = 0;
-    unsigned long long tl_a = 0, tl_b = 0, tl_c = 0, tl_d = 0;
+    unsigned long long tl_a = 0, tl_b = 0, tl_c = 0, tl_d = 0, tl_big = 0, tl_tree = 0, tl_loop = 0;
     unsigned int tl_units = 0, tl_iters = 0;
 #endif
     if (STATS) {
@@ -897,6 +911,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 #ifdef RTGO_TIMELINE
             if (tl_iters == 1 && tl_c == 0) tl_c = wall_clock64();
             tl_iters += 1;
+            const unsigned long long tl_i0 = wall_clock64();
             tl_lanes += (unsigned long long)__popcll(__ballot(active));
 #endif
             if (active) {
@@ -904,7 +919,11 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                 c_rays += 1;
                 bool hit;
                 if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h, c_nodes, c_tests);
+                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h, c_nodes, c_tests
+#ifdef RTGO_TIMELINE
+                                            , tl_big, tl_tree
+#endif
+                );
                 if (STATS && hit) c_hits += 1;
                 any_hit = any_hit || hit;
 
@@ -1080,6 +1099,9 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                     active = false;
                 }
             }
+#ifdef RTGO_TIMELINE
+            tl_loop += wall_clock64() + (result.x == 12345.0f ? 1 : 0) - tl_i0;
+#endif
         }
         // color += payload, in sample order (kernel.cu:232): every lane of a pixel's group walks the group's results
         const unsigned int cnt = (nn - pass * nn_eff) < nn_eff ? (nn - pass * nn_eff) : nn_eff;
@@ -1107,7 +1129,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 #ifdef RTGO_TIMELINE
     if (lane == 0) {
         unsigned long long* r = p.timeline + 16ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-        r[8] = tl_a; r[9] = tl_b; r[10] = tl_c; r[11] = tl_d;
+        r[8] = tl_a; r[9] = tl_b; r[10] = tl_c; r[11] = tl_d; r[12] = tl_big; r[13] = tl_tree; r[14] = tl_loop;
         r[0] = tl_t0; r[1] = tl_t1; r[2] = tl_first; r[3] = wall_clock64(); r[4] = tl_units | ((unsigned long long)tl_hot << 32); r[5] = tl_iters; r[6] = tl_lanes;
         r[7] = tl_qwait | ((tl_cold ? tl_cold - tl_t0 : 0ull) << 32);
     }

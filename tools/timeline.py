@@ -51,6 +51,9 @@ print("queue wait / wave [us]  " + pc(qwait))
 print("ray iterations per wave " + pc(iters))
 print("waves with no unit: %d; total units %d; iterations/unit %.2f; live lanes/iteration %.1f of 64" %
       ((units == 0).sum(), units.sum(), iters.sum() / max(units.sum(), 1), lanes.sum() / max(iters.sum(), 1)))
+big, tree, loop = r[:, 12].sum(), r[:, 13].sum(), r[:, 14].sum()
+if loop > 0:
+    print("ray-loop time: up-front list %.1f %%, tree walk %.1f %%, shading + bookkeeping %.1f %%; per iteration %.2f us" % (100.0 * big / loop, 100.0 * tree / loop, 100.0 * (loop - big - tree) / loop, us(loop) / max(iters.sum(), 1)))
 busy = us(r[:, 3] - r[:, 2])[units > 0]
 print("busy time first unit -> end per wave [us] " + pc(busy) + "   sum/(waves*span) = %.2f" % (busy.sum() / (n * end.max())))
 # how much of the span is tail: time after which fewer than half of the waves are still running
