@@ -40,6 +40,7 @@ struct rtgo_ctx {
     int lbvh_depth = 0;
     int fast_depth = 0;
     int n_small = 0;
+    int n_big_pairs = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};  // tight world bounds of the scene (min xyz, max xyz)
     int leaf_budget = kDefaultLeafBudget;
     LightRec* d_lights = nullptr;
@@ -312,13 +313,14 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), 0, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget, c->d_meta);
     RTGO_HIP(c, hipGetLastError());
-    int meta[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int meta[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     const int depth = meta[0];
     c->lbvh_depth = depth;
     c->fast_depth = meta[1];
     c->n_small = meta[2];
+    c->n_big_pairs = meta[9];
     std::memcpy(c->bounds, &meta[3], sizeof c->bounds);
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
@@ -484,6 +486,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.fnodes = c->d_fnodes;
     p.fprims = c->d_fprims;
     p.n_small = c->n_small;
+    p.n_big_pairs = c->n_big_pairs;
     p.stack_depth = stats ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
     p.lights = c->d_lights;
     p.accum = c->d_accum;

@@ -46,6 +46,7 @@ struct LaunchParams {
     const float4* fprims;           // 4 float4 per primitive in Morton order: rows 0..2 of M^-1, (bits(type), bits(SBT index), 0, 0)
     int stack_depth;                // per-lane LDS stack entries this launch needs
     int n_small;                    // fast walk: fprims [0, n_small) are in the tree, [n_small, n_prims) are tested up front
+    int n_big_pairs;                // ... of which the first 2*n_big_pairs records are pairs of opposite rectangles (pair_test)
     const LightRec* lights;
     float4* accum;
     uchar4* image;
@@ -472,6 +473,63 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
     }
 }
 
+// Two rectangles that the build has put side by side because their normals are opposite (the two faces of a box, floor and
+// ceiling, left and right wall).  A rectangle is one-sided: its test starts with d.y < 0 in object space (kernel.cu:394-400),
+// and d.y is the ray direction against the world normal, so at most one of the two can get past that first test -- the
+// rest of the test then runs once, on whichever it is, instead of twice with half of the lanes masked off.  Exactly the
+// tests leaf_test() would make, on the same values: when rounding lets BOTH through, both are tested.
+template <typename Ptr>
+__device__ __forceinline__ void pair_test(Ptr fp, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+    const float4 r1a = fp[4 * pos + 1], r1b = fp[4 * pos + 5];
+    const float dya = r1a.x * wd.x + r1a.y * wd.y + r1a.z * wd.z;
+    const float dyb = r1b.x * wd.x + r1b.y * wd.y + r1b.z * wd.z;
+    const bool fa = dya < 0.0f, fb = dyb < 0.0f;
+    if (fa && fb) {
+        leaf_test(fp, pos, wo, wd, tmin, best);
+        leaf_test(fp, pos + 1, wo, wd, tmin, best);
+        return;
+    }
+    if (fa || fb) {
+        const float4 r1 = fa ? r1a : r1b;
+        const float dy = fa ? dya : dyb;
+        const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
+        if (oy > 0.0f) {
+            const float t = (0.0f - oy) / dy;
+            const float4 ma = fp[4 * pos + 3], mb = fp[4 * pos + 7];
+            const int orig = __float_as_int(fa ? ma.y : mb.y);
+            if (t > 0.0001f && closer(t, orig, tmin, best)) {
+                const float4 r0a = fp[4 * pos + 0], r0b = fp[4 * pos + 4], r2a = fp[4 * pos + 2], r2b = fp[4 * pos + 6];
+                const float4 r0 = fa ? r0a : r0b, r2 = fa ? r2a : r2b;
+                const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
+                const float ox = r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, oz = r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w;
+                const float px = ox + t * dx, pz = oz + t * dz;
+                const float u = px + 0.5f, v = -(pz - 0.5f);
+                if (0.0f < u && u < 1.0f && 0.0f < v && v < 1.0f) {
+                    best.t = t;
+                    best.nobj = mk(0.0f, 1.0f, 0.0f);
+                    best.pos = fa ? pos : pos + 1;
+                    best.orig = orig;
+                }
+            }
+        }
+    }
+}
+
+// the records [first, first + cnt) of one leaf (or of the up-front list): npairs pairs first, then single primitives
+template <bool LIST, typename Ptr>
+__device__ __forceinline__ void leaf_range(Ptr fp, int first, int cnt, int npairs, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+#pragma unroll 1
+    for (int k = 0; k < npairs; ++k) pair_test(fp, first + 2 * k, wo, wd, tmin, best);
+    if (LIST) {
+#pragma unroll 2
+        for (int k = 2 * npairs; k < cnt; ++k) leaf_test(fp, first + k, wo, wd, tmin, best);
+    } else {
+        for (int k = 2 * npairs; k < cnt; ++k) leaf_test(fp, first + k, wo, wd, tmin, best);
+    }
+}
+
 // conservative slab test: t = fma(b, 1/d, -o/d) with the hardware reciprocal
 __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id, v3 noid, float tmin, float tmax, float& tn_out)
 {
@@ -494,7 +552,7 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
                                                  const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int bshift,
-                                                 int n_small, int n_prims, v3 o, v3 d, float tmin, float tmax, Hit& out,
+                                                 int n_small, int n_prims, int n_big_pairs, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests
 #ifdef RTGO_TIMELINE
                                                  , unsigned long long& tl_big, unsigned long long& tl_tree
@@ -516,8 +574,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     // g_fprims is a read-only kernel argument, so the records arrive by scalar loads (s_load_dwordx4) into SGPRs: no LDS
     // traffic, no VGPRs for the matrices, and the loads of the next primitives overlap the tests of the current ones.
     // It also gives every ray a closest-hit bound before it enters the tree.
-#pragma unroll 2
-    for (int k = n_small; k < n_prims; ++k) leaf_test(g_fprims, k, o, d, tmin, best);
+    leaf_range<true>(g_fprims, n_small, n_prims - n_small, n_big_pairs, o, d, tmin, best);
 #ifdef RTGO_FAST_COUNTERS
     dbg_tests += (unsigned int)(n_prims - n_small);
 #endif
@@ -577,11 +634,11 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
             }
         }
         if (have) {
-            const int first = left, cnt = -right;
+            const int first = left, cnt = (-right) & 0xFFF, npairs = (-right) >> 12;   // leaf link = -(count | pairs << 12)
 #ifdef RTGO_FAST_COUNTERS
             dbg_tests += (unsigned int)cnt;
 #endif
-            for (int k = 0; k < cnt; ++k) leaf_test(s_fprims, first + k, o, d, tmin, best);
+            leaf_range<false>(s_fprims, first, cnt, npairs, o, d, tmin, best);
             have = pop();
         }
     }
@@ -919,7 +976,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                 c_rays += 1;
                 bool hit;
                 if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, ro, rd, tmin, tmax, h, c_nodes, c_tests
+                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, h, c_nodes, c_tests
 #ifdef RTGO_TIMELINE
                                             , tl_big, tl_tree
 #endif
@@ -1271,6 +1328,8 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     __shared__ int s_wt[2 * kMaxPrims];                 // fast walk: cost weight of each subtree
     __shared__ short s_lo[kMaxPrims], s_hi[kMaxPrims];  // Morton range covered by each internal node
     __shared__ unsigned char s_flag[kMaxPrims];         // fast walk: 1 = "big" primitive kept out of the tree
+    __shared__ unsigned short s_order[kMaxPrims];       // fast walk: primitive at each record position (pairs side by side)
+    __shared__ unsigned char s_used[kMaxPrims];
     __shared__ int s_depth, s_count;
     // the bounds reductions run while s_nbox is not in use: borrow its storage (keeps static LDS under 64 KiB)
     float(*s_red)[kMaxPrims] = reinterpret_cast<float(*)[kMaxPrims]>(&s_nbox[0][0]);
@@ -1496,9 +1555,72 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
             }
             atomicMax(&s_depth, fdep);
         }
+        // Record order inside every group the walk scans linearly -- the up-front list and each maximal collapsed leaf:
+        // rectangles with opposite normals side by side (pair_test), pairs first, the rest after them.  One thread per group.
+        // A leaf is only paired when ALL its records pair up (a whole box): lanes of a wave scan different leaves side by side,
+        // and leaves of mixed composition would make them take turns in the pair loop and the single loop (checkered: +9 %).
         if (i < n) {
-            // Morton-ordered traversal record (inverse rows were written to out_prims by the primitive's own thread above)
-            const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
+            s_order[i] = (unsigned short)(s_keys[i] & 0xFFFFFFFFu);
+            s_used[i] = 0;
+            s_visit[i] = 0;   // (build_tree's arrival counters are no longer needed: pairs per node from here on)
+        }
+        if (i == 0) out_meta[9] = 0;
+        __syncthreads();
+        {
+            int g_lo = 0, g_hi = -1;
+            const bool list = (i == kMaxPrims - 1);
+            if (list) {
+                g_lo = n_small;
+                g_hi = n - 1;
+            } else if (i < leaf0 && s_wt[i] <= leaf_budget && (s_parent[i] < 0 || s_wt[s_parent[i]] > leaf_budget)) {
+                g_lo = s_lo[i];
+                g_hi = s_hi[i];
+            }
+            if (g_hi > g_lo) {
+                auto prim_at = [&](int pos) { return (int)(s_keys[pos] & 0xFFFFFFFFu); };
+                auto is_rect = [&](int pos) { return prims[prim_at(pos)].type == 2u; };
+                auto normal_of = [&](int pos) {   // world normal of a rectangle = row 1 of M^-1 (TransformNormal of (0,1,0))
+                    const float4 r = out_prims[6 * prim_at(pos) + 1];
+                    const float l = sqrtf(r.x * r.x + r.y * r.y + r.z * r.z);
+                    return l > 0.0f ? mk(r.x / l, r.y / l, r.z / l) : mk(0.0f, 0.0f, 0.0f);
+                };
+                int out = g_lo;
+                for (int a = g_lo; a <= g_hi; ++a) {
+                    if (s_used[a] || !is_rect(a)) continue;
+                    const v3 na = normal_of(a);
+                    int bsel = -1;
+                    float bdot = -0.9999f;
+                    for (int b = a + 1; b <= g_hi; ++b) {
+                        if (s_used[b] || !is_rect(b)) continue;
+                        const float dt = vdot(na, normal_of(b));
+                        if (dt < bdot) {
+                            bdot = dt;
+                            bsel = b;
+                        }
+                    }
+                    if (bsel >= 0) {
+                        s_used[a] = 1;
+                        s_used[bsel] = 1;
+                        s_order[out] = (unsigned short)prim_at(a);
+                        s_order[out + 1] = (unsigned short)prim_at(bsel);
+                        out += 2;
+                    }
+                }
+                const int npairs = (out - g_lo) / 2;
+                if (list || 2 * npairs == g_hi - g_lo + 1) {
+                    for (int a = g_lo; a <= g_hi; ++a)
+                        if (!s_used[a]) s_order[out++] = (unsigned short)prim_at(a);
+                    if (list) out_meta[9] = npairs;
+                    else s_visit[i] = npairs;
+                } else {
+                    for (int a = g_lo; a <= g_hi; ++a) s_order[a] = (unsigned short)prim_at(a);   // leave the leaf as it was
+                }
+            }
+        }
+        __syncthreads();
+        if (i < n) {
+            // traversal record (inverse rows were written to out_prims by the primitive's own thread above)
+            const int prim = (int)s_order[i];
             out_fprims[4 * i + 0] = out_prims[6 * prim + 0];
             out_fprims[4 * i + 1] = out_prims[6 * prim + 1];
             out_fprims[4 * i + 2] = out_prims[6 * prim + 2];
@@ -1511,7 +1633,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
                 fr = -1;
             } else if (s_wt[k] <= leaf_budget) {
                 fl = s_lo[k];
-                fr = -((int)s_hi[k] - (int)s_lo[k] + 1);
+                fr = -(((int)s_hi[k] - (int)s_lo[k] + 1) | (s_visit[k] << 12));   // count | pairs << 12
             } else {
                 fl = s_left[k];
                 fr = s_right[k];
