@@ -1557,17 +1557,22 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         }
         // Record order inside every group the walk scans linearly -- the up-front list and each maximal collapsed leaf:
         // rectangles with opposite normals side by side (pair_test), pairs first, the rest after them.  One thread per group.
-        // A leaf is only paired when ALL its records pair up (a whole box): lanes of a wave scan different leaves side by side,
-        // and leaves of mixed composition would make them take turns in the pair loop and the single loop (checkered: +9 %).
+        // Leaves are only paired when EVERY multi-record leaf of the scene pairs up completely (whole boxes): the lanes of a wave
+        // scan different leaves side by side, and with leaves of both kinds they take turns in the pair loop and the single
+        // loop (checkered, whose Morton leaves cut across its 64 cubes: +9 %).  The up-front list is scanned by all lanes
+        // together and is always paired.
         if (i < n) {
             s_order[i] = (unsigned short)(s_keys[i] & 0xFFFFFFFFu);
             s_used[i] = 0;
             s_visit[i] = 0;   // (build_tree's arrival counters are no longer needed: pairs per node from here on)
         }
-        if (i == 0) out_meta[9] = 0;
+        if (i == 0) {
+            out_meta[9] = 0;
+            s_count = 0;   // leaves that do not pair up completely
+        }
         __syncthreads();
+        int g_lo = 0, g_hi = -1;
         {
-            int g_lo = 0, g_hi = -1;
             const bool list = (i == kMaxPrims - 1);
             if (list) {
                 g_lo = n_small;
@@ -1613,9 +1618,14 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
                     if (list) out_meta[9] = npairs;
                     else s_visit[i] = npairs;
                 } else {
-                    for (int a = g_lo; a <= g_hi; ++a) s_order[a] = (unsigned short)prim_at(a);   // leave the leaf as it was
+                    atomicAdd(&s_count, 1);
                 }
             }
+        }
+        __syncthreads();
+        if (s_count > 0 && i != kMaxPrims - 1 && g_hi > g_lo) {   // mixed scene: leave every leaf as it was
+            for (int a = g_lo; a <= g_hi; ++a) s_order[a] = (unsigned short)(s_keys[a] & 0xFFFFFFFFu);
+            s_visit[i] = 0;
         }
         __syncthreads();
         if (i < n) {
