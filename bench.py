@@ -31,7 +31,8 @@ def pmc_traffic(scene, W, H, mode, N):
         try:
             j = json.load(open(f))
             if key in j["bench"]["config"]["workload"] and "hbm_traffic_bytes_per_launch" in j:
-                best = (j["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+                best = (j["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT),
+                        {k: round(j[k], 4) for k in ("valu_issue_busy", "valu_lane_utilisation") if k in j})
         except Exception:
             pass
     return best
@@ -272,6 +273,8 @@ def main():
                          "V": round(Vbar, 3), "T": round(Tbar, 3), "h": round(hbar, 4),
                          "achieved_min": round((rays_per_launch * 168 + W * H * A_px) / world / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0,
                          "mrays_roofline": round(HBM_PEAK_GBS * 1e3 / A_ray, 1),
+                         # what actually binds the kernel (PMC of the committed profile): vector issue slots filled, lanes live in them
+                         "secondary": ({"bound": "valu issue", **traffic[2]} if traffic and world == 1 and traffic[2] else None),
                          "note": "algorithmic bytes (SURVEY 8d) per launch / HIP-event kernel time; the scene is LDS-resident so physical HBM traffic is only the framebuffer"},
         }
         if rehearse:
