@@ -491,3 +491,86 @@ def test_background_culling_random_cameras(capi, oracle, name):
             culled += int(st["hits"] == 0 or st["rays_total"] < 2 * n * n * len(rows) * w)
     ctx.close()
     print(name, "launches dominated by background:", culled)
+
+
+def _box_scene(oracle, seed, W, H, n_boxes, with_spheres, tilt):
+    """a room (five big rectangles + ceiling light) holding random boxes of six rectangles each, optionally spheres between
+    them (mixed leaves) and a pair of nearly -- not exactly -- opposite rectangles (both can face a grazing ray)"""
+    rng = np.random.RandomState(1000 + seed)
+    L = oracle.lib()
+    f = oracle.fptr
+
+    def mat(kind, *a):
+        out = np.zeros(16, dtype=np.float32)
+        getattr(L, "oracle_mat_" + kind)(*[np.float32(v) for v in a], f(out))
+        return out
+
+    def mul(*ms):
+        acc = ms[0]
+        for m in ms[1:]:
+            out = np.zeros(16, dtype=np.float32)
+            L.oracle_mat_mul(f(acc), f(m), f(out))
+            acc = out
+        return acc
+
+    hp = np.pi / 2
+    faces = [mul(mat("translate", 0, .5, 0)), mul(mat("translate", 0, -.5, 0), mat("rotate", np.pi, 1, 0, 0)),
+             mul(mat("translate", .5, 0, 0), mat("rotate", -hp, 0, 0, 1)), mul(mat("translate", -.5, 0, 0), mat("rotate", hp, 0, 0, 1)),
+             mul(mat("translate", 0, 0, .5), mat("rotate", hp, 1, 0, 0)), mul(mat("translate", 0, 0, -.5), mat("rotate", -hp, 1, 0, 0))]
+    types, M, mats = [], [], []
+
+    def add(t, m, kd=(0.7, 0.7, 0.7), kr=0.2, spec=1.0, Le=0.0):
+        types.append(t)
+        M.append(m)
+        mats.append([kd[0], kd[1], kd[2], kr, kr, kr, spec, Le, Le, Le])
+
+    # room: inward-facing walls (the unit rectangle faces +y), floor, and the light as the ceiling
+    add(2, mul(mat("translate", 0, -4, 0), mat("scale", 12, 1, 12)))
+    ceil = mul(mat("translate", 0, 4, 0), mat("rotate", np.pi, 1, 0, 0), mat("scale", 12, 1, 12))
+    add(2, ceil, kd=(0, 0, 0), kr=0, Le=6.0)
+    add(2, mul(mat("translate", -6, 0, 0), mat("rotate", -hp, 0, 0, 1), mat("scale", 8, 1, 12)), kd=(0.8, 0.2, 0.2))
+    add(2, mul(mat("translate", 6, 0, 0), mat("rotate", hp, 0, 0, 1), mat("scale", 8, 1, 12)), kd=(0.2, 0.8, 0.2))
+    add(2, mul(mat("translate", 0, 0, -6), mat("rotate", hp, 1, 0, 0), mat("scale", 12, 1, 8)))
+    for b in range(n_boxes):
+        ax = rng.uniform(-1, 1, 3)
+        ax /= np.linalg.norm(ax)
+        box = mul(mat("translate", *rng.uniform(-4, 4, 3)), mat("rotate", rng.uniform(-3, 3), *ax), mat("scale", *rng.uniform(0.5, 2.5, 3)))
+        kd = rng.uniform(0.2, 1.0, 3)
+        for face in faces:
+            add(2, mul(box, face), kd=kd, kr=float(rng.choice([0.0, 0.6])), spec=float(rng.choice([1.0, 200.0])))
+    if with_spheres:
+        for s in range(8):
+            add(3, mul(mat("translate", *rng.uniform(-4, 4, 3)), mat("scale", *([rng.uniform(0.3, 0.9)] * 3))), kd=rng.uniform(0.2, 1, 3))
+    if tilt:
+        base = mul(mat("translate", 2.5, -1.0, 2.0), mat("scale", 3, 1, 3))
+        add(2, base, kd=(0.9, 0.9, 0.2))
+        add(2, mul(mat("translate", 2.5, -1.6, 2.0), mat("rotate", np.pi + 0.006, 1, 0, 0), mat("scale", 3, 1, 3)), kd=(0.2, 0.9, 0.9))
+    cam = oracle.scene_tables(oracle.scene("cornell", W, H))["cam"]
+    sc = oracle.scene_from_tables(np.array(types), np.stack(M), np.array(mats, dtype=np.float32),
+                                  np.stack([oracle.light_from_matrix(ceil, falloff=0.02)]), cam, (0.02, 0.02, 0.05))
+    return sc, oracle.scene_tables(sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [(1, 2, False, False), (2, 5, False, True), (3, 9, True, False), (4, 14, True, True), (5, 30, False, False)])
+def test_paired_rectangles_in_boxes(capi, oracle, case):
+    """the fast walk tests rectangles with opposite normals as one pair (up-front list always; leaves when every leaf is a whole
+    box): same pixels as the canonical walk bit for bit, with whole-box leaves, mixed leaves, boxes cut by Morton leaves
+    and a pair that is not quite parallel; and both agree with the oracle"""
+    seed, n_boxes, with_spheres, tilt = case
+    W, H, n = 96, 72, 2
+    sc, t = _box_scene(oracle, seed, W, H, n_boxes, with_spheres, tilt)
+    ctx = capi.Context(0)
+    ctx.set_scene(t["type"], t["M"], t["mat"], None)
+    ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
+    ctx.set_background(t["bg"])
+    ctx.set_lights(t["lights"])
+    prev = np.full((H, W, 4), 0.25, np.float32)
+    for path, amb in ((True, False), (False, False)):
+        canon, cimg = gpu_render(capi, ctx, W, H, n, 1, path, amb, stats=True, prev=prev)
+        fast, fimg = gpu_render(capi, ctx, W, H, n, 1, path, amb, stats=False, prev=prev)
+        assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), "fast walk != canonical walk"
+        assert np.array_equal(fimg, cimg)
+        racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 1, path=path, ambient=amb, mode=1), accum_prev=prev)
+        assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="boxes %s path=%s" % (case, path))
+    ctx.close()
