@@ -479,8 +479,11 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
 // rest of the test then runs once, on whichever it is, instead of twice with half of the lanes masked off.  Exactly the
 // tests leaf_test() would make, on the same values: when rounding lets BOTH through, both are tested.
 template <typename Ptr>
-__device__ __forceinline__ void pair_test(Ptr fp, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
+__device__ __forceinline__ void pair_test(Ptr fp, const float4* __restrict__ lds, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
 {
+    // fp: where the two normals come from (the up-front list reads them through scalar loads); lds: the LDS copy of the same
+    // records, from which each lane then reads the ONE rectangle it goes on with (a per-lane address costs one ds_read; choosing
+    // between two rows held in SGPRs costs three VALU instructions per float)
     const float4 r1a = fp[4 * pos + 1], r1b = fp[4 * pos + 5];
     const float dya = r1a.x * wd.x + r1a.y * wd.y + r1a.z * wd.z;
     const float dyb = r1b.x * wd.x + r1b.y * wd.y + r1b.z * wd.z;
@@ -491,16 +494,15 @@ __device__ __forceinline__ void pair_test(Ptr fp, int pos, v3 wo, v3 wd, float t
         return;
     }
     if (fa || fb) {
-        const float4 r1 = fa ? r1a : r1b;
+        const int sel = fa ? pos : pos + 1;
+        const float4 r1 = lds[4 * sel + 1];
         const float dy = fa ? dya : dyb;
         const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
         if (oy > 0.0f) {
             const float t = (0.0f - oy) / dy;
-            const float4 ma = fp[4 * pos + 3], mb = fp[4 * pos + 7];
-            const int orig = __float_as_int(fa ? ma.y : mb.y);
+            const int orig = __float_as_int(lds[4 * sel + 3].y);
             if (t > 0.0001f && closer(t, orig, tmin, best)) {
-                const float4 r0a = fp[4 * pos + 0], r0b = fp[4 * pos + 4], r2a = fp[4 * pos + 2], r2b = fp[4 * pos + 6];
-                const float4 r0 = fa ? r0a : r0b, r2 = fa ? r2a : r2b;
+                const float4 r0 = lds[4 * sel + 0], r2 = lds[4 * sel + 2];
                 const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
                 const float ox = r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, oz = r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w;
                 const float px = ox + t * dx, pz = oz + t * dz;
@@ -508,7 +510,7 @@ __device__ __forceinline__ void pair_test(Ptr fp, int pos, v3 wo, v3 wd, float t
                 if (0.0f < u && u < 1.0f && 0.0f < v && v < 1.0f) {
                     best.t = t;
                     best.nobj = mk(0.0f, 1.0f, 0.0f);
-                    best.pos = fa ? pos : pos + 1;
+                    best.pos = sel;
                     best.orig = orig;
                 }
             }
@@ -518,10 +520,10 @@ __device__ __forceinline__ void pair_test(Ptr fp, int pos, v3 wo, v3 wd, float t
 
 // the records [first, first + cnt) of one leaf (or of the up-front list): npairs pairs first, then single primitives
 template <bool LIST, typename Ptr>
-__device__ __forceinline__ void leaf_range(Ptr fp, int first, int cnt, int npairs, v3 wo, v3 wd, float tmin, FastHit& best)
+__device__ __forceinline__ void leaf_range(Ptr fp, const float4* __restrict__ lds, int first, int cnt, int npairs, v3 wo, v3 wd, float tmin, FastHit& best)
 {
 #pragma unroll 1
-    for (int k = 0; k < npairs; ++k) pair_test(fp, first + 2 * k, wo, wd, tmin, best);
+    for (int k = 0; k < npairs; ++k) pair_test(fp, lds, first + 2 * k, wo, wd, tmin, best);
     if (LIST) {
 #pragma unroll 2
         for (int k = 2 * npairs; k < cnt; ++k) leaf_test(fp, first + k, wo, wd, tmin, best);
@@ -574,7 +576,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     // g_fprims is a read-only kernel argument, so the records arrive by scalar loads (s_load_dwordx4) into SGPRs: no LDS
     // traffic, no VGPRs for the matrices, and the loads of the next primitives overlap the tests of the current ones.
     // It also gives every ray a closest-hit bound before it enters the tree.
-    leaf_range<true>(g_fprims, n_small, n_prims - n_small, n_big_pairs, o, d, tmin, best);
+    leaf_range<true>(g_fprims, s_fprims, n_small, n_prims - n_small, n_big_pairs, o, d, tmin, best);
 #ifdef RTGO_FAST_COUNTERS
     dbg_tests += (unsigned int)(n_prims - n_small);
 #endif
@@ -638,7 +640,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
 #ifdef RTGO_FAST_COUNTERS
             dbg_tests += (unsigned int)cnt;
 #endif
-            leaf_range<false>(s_fprims, first, cnt, npairs, o, d, tmin, best);
+            leaf_range<false>(s_fprims, s_fprims, first, cnt, npairs, o, d, tmin, best);
             have = pop();
         }
     }
