@@ -790,7 +790,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     const float4* s_mat = s_mat_w;
     // small scenes (the 5-waves-per-SIMD variant): per-level path records live in LDS, [4 words x kMaxLevels][lane], instead of
     // 15-20 VGPRs -- that is what lets the allocation fit 96 registers without spilling to scratch
-    constexpr bool LVLDS = (WPE == 5);
+    constexpr bool LVLDS = (WPE >= 5);
     float* s_lv = reinterpret_cast<float*>(s_lights + kMaxLights) + threadIdx.x;
 
     const int tid = threadIdx.x;
