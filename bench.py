@@ -103,10 +103,18 @@ def main():
     ap.add_argument("--mode", default="path", choices=["path", "distributed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-frame band gather (diagnostic)")
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="developer check on a 1-GPU box: run the N>1 machinery (RCCL process group, comm stream, triple-buffered "
+                         "bands, gather + de-interleave every frame) with a world of one rank. The JSON line is marked.")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="developer rehearsal of the N>1 code path on a 1-GPU box: every rank uses cuda:0 and the gather goes "
                          "through gloo on host copies. The JSON line is marked and is NOT a measurement.")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: libraries that print there (RCCL's version banner at start-up) go to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -121,11 +129,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible; the hot path has no CPU fallback")
     rehearse = args.rehearse_on_one_gpu
+    multi = world > 1 or args.single_rank_collectives   # the N>1 machinery is on
+    if args.single_rank_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -159,29 +173,29 @@ def main():
     assert stream.cuda_stream != 0
     ctx.set_stream(stream.cuda_stream)
     full_image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    row_index = bands.full_row_index(H, band_h, world, rows_pad, dev) if (rank == 0 and world > 1) else None
+    row_index = bands.full_row_index(H, band_h, world, rows_pad, dev) if (rank == 0 and multi) else None
 
     def frame(f, stats=False):
         # N > 1: leave 8 CUs' worth of workgroup slots free so that RCCL's kernels can run beside the persistent megakernel
         return capi.make_frame(W, H, N, f, path, False, None, (band_h, world, rank), stats=stats,
-                               reserve_cus=(8 if world > 1 and not stats else 0))
+                               reserve_cus=(8 if multi and not stats else 0))
 
     # N > 1: the 8-bit bands are triple-buffered so that the gather of frame f (comm stream -> RCCL) overlaps the
     # megakernel of frame f+1 (compute stream).  Every frame is still gathered and de-interleaved on rank 0 inside the
     # timed region; the accumulation buffer is single (frame f+1 reads what frame f wrote, same stream).
     NBUF = 3
-    images = [image] + [torch.zeros_like(image) for _ in range(NBUF - 1)] if world > 1 else [image]
-    comm = torch.cuda.Stream(dev, priority=-1) if world > 1 else None
+    images = [image] + [torch.zeros_like(image) for _ in range(NBUF - 1)] if multi else [image]
+    comm = torch.cuda.Stream(dev, priority=-1) if multi else None
     gathered = [None] * NBUF   # event: the gather that last read images[b] has completed
-    gather_ws = (torch.empty((world * rows_pad, W, 4), dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None)
+    gather_ws = (torch.empty((world * rows_pad, W, 4), dtype=torch.uint8, device=dev) if (multi and rank == 0) else None)
 
     def step(f):
-        b = f % NBUF if world > 1 else 0
-        if world > 1 and gathered[b] is not None:
+        b = f % NBUF if multi else 0
+        if multi and gathered[b] is not None:
             stream.wait_event(gathered[b])            # WAR: do not overwrite a band buffer a gather is still reading
         ctx.bind_output(accum.data_ptr(), images[b].data_ptr(), rows_pad * W)
         ctx.launch(frame(f))
-        if world > 1 and not args.no_gather:
+        if multi and not args.no_gather:
             done = torch.cuda.Event()
             done.record(stream)
             comm.wait_event(done)
@@ -199,7 +213,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -211,7 +225,7 @@ def main():
     st = ctx.stats()
     rdev = torch.device("cpu") if rehearse else dev   # gloo reduces host tensors
     cnt = torch.tensor([st["rays_total"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(cnt)
     rays_s, nodes_s, tests_s, hits_s, occl_s = [float(x) for x in cnt.tolist()]
     Vbar, Tbar, hbar = nodes_s / rays_s, tests_s / rays_s, hits_s / rays_s
@@ -234,7 +248,7 @@ def main():
     tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
     rr = torch.tensor([float(st["rays_total"]), float(st["rays_culled"])], dtype=torch.float64, device=rdev)
     km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1)], dtype=torch.float64, device=rdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         dist.all_reduce(km, op=dist.ReduceOp.MAX)
@@ -257,7 +271,7 @@ def main():
             "config": {"workload": "%s %dx%d --mode=%s --sample=%d (%d spp), progressive frames %d..%d" %
                                    (args.scene, W, H, args.mode, N, N * N, args.warmup, args.warmup + args.steps - 1),
                        "primitives": int(len(t["type"])), "tiling": "4-row bands interleaved over %d GPU(s)" % world,
-                       "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (world > 1 and not args.no_gather) else "none",
+                       "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (multi and not args.no_gather) else "none",
                        "rays_per_frame": int(round(rays_per_launch)),
                        # primary rays of pixels outside the screen rectangle of the scene's bounds: counted (the reference traces
                        # them, they miss) but answered by that rectangle instead of a traversal; the rate without them is given too
@@ -277,6 +291,9 @@ def main():
                          "secondary": ({"bound": "valu issue", **traffic[2]} if traffic and world == 1 and traffic[2] else None),
                          "note": "algorithmic bytes (SURVEY 8d) per launch / HIP-event kernel time; the scene is LDS-resident so physical HBM traffic is only the framebuffer"},
         }
+        if args.single_rank_collectives:
+            out["single_rank_collectives"] = "N>1 machinery with a world of one rank (developer check): NOT the N=1 measurement"
+            out["gathered_frame_matches_local_image"] = bool(torch.equal(full_image, images[(args.warmup + args.steps - 1) % NBUF][:H]))
         if rehearse:
             out["rehearsal"] = "all ranks on cuda:0, gloo gather through host memory: NOT a measurement"
             # correctness of the N>1 path: the gathered 8-bit frame must equal a whole-image render of the same frame
@@ -294,8 +311,9 @@ def main():
             ctx.launch(capi.make_frame(W, H, N, 0, path, False, None, (band_h, 1, 0)))
             ctx.sync()
             out["cpu_baseline"]["gpu_frame0_vs_oracle"] = parity_against(ref_acc, ref_win, scratch_a[:H].cpu().numpy())
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

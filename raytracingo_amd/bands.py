@@ -28,7 +28,7 @@ def gather_bands(local, h, band_h, dist, dst=0, group=None, out=None, row_index=
     import torch
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if world == 1:
+    if world == 1 and out is None and workspace is None:
         return local[:h]
     if rank == dst:
         rows_pad = local.shape[0]

@@ -574,3 +574,26 @@ def test_paired_rectangles_in_boxes(capi, oracle, case):
         racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 1, path=path, ambient=amb, mode=1), accum_prev=prev)
         assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="boxes %s path=%s" % (case, path))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_bench_contract_and_rccl_path_on_one_gpu():
+    """bench.py prints exactly one JSON line on stdout with the contract's keys (+ roofline), and its N>1 machinery -- RCCL
+    process group, comm stream, triple-buffered bands, gather + de-interleave of every frame -- runs with a world of one rank
+    and hands back the frame that was rendered"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--width", "320", "--height", "180", "--no-cpu-baseline"]
+    for extra in ([], ["--single-rank-collectives"]):
+        r = subprocess.run(base + extra, capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1, r.stdout
+        j = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline"):
+            assert k in j, k
+        assert j["n_gpus"] == 1 and j["steps"] == 4 and j["value"] > 0 and j["roofline"]["frac"] > 0
+        if extra:
+            assert j["gathered_frame_matches_local_image"] is True
