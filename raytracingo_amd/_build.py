@@ -29,15 +29,42 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+class _build_lock:
+    """one builder at a time (N ranks of a multi-GPU launch import the package together); results appear by atomic rename"""
+
+    def __enter__(self):
+        import fcntl
+        self.f = open(os.path.join(PKG, ".build.lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
+def _run_to(out, cmd_before_out, cmd_after_out, verbose):
+    tmp = "%s.tmp.%d" % (out, os.getpid())
+    cmd = cmd_before_out + ["-o", tmp] + cmd_after_out
+    if verbose:
+        print(" ".join(cmd_before_out + ["-o", out] + cmd_after_out))
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+
+
 def build_hip(force=False, verbose=False):
     src = os.path.join(PKG, "csrc", "rtgo_capi.hip")
     deps = [src, os.path.join(PKG, "csrc", "rtgo_device.h"), os.path.join(ROOT, "include", "rtgo.h")]
     out = os.path.join(PKG, "librtgo_hip.so")
     if force or _stale(out, deps):
-        cmd = [HIPCC] + HIP_FLAGS + ["-o", out, src]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        with _build_lock():
+            if force or _stale(out, deps):
+                _run_to(out, [HIPCC] + HIP_FLAGS, [src], verbose)
     return out
 
 
@@ -55,18 +82,17 @@ def build_host(force=False, verbose=False):
                                                                               os.path.join(ROOT, "include", "rtgo_host.h")]
     out = os.path.join(PKG, "librtgo_host.so")
     if srcs and (force or _stale(out, srcs + hdrs)):
-        cmd = ["g++"] + HOST_FLAGS + ["-shared", "-I" + os.path.join(ROOT, "include"), "-I" + d, "-o", out] + srcs + ["-L" + PKG, "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        with _build_lock():
+            if force or _stale(out, srcs + hdrs):
+                _run_to(out, ["g++"] + HOST_FLAGS + ["-shared", "-I" + os.path.join(ROOT, "include"), "-I" + d],
+                        srcs + ["-L" + PKG, "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"], verbose)
     exe = os.path.join(PKG, "rtgo_engine")
     main = os.path.join(d, "main.cpp")
     if os.path.exists(main) and (force or _stale(exe, [main, out] + hdrs)):
-        cmd = ["g++"] + HOST_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + d, "-o", exe, main,
-                                      "-L" + PKG, "-lrtgo_host", "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        with _build_lock():
+            if force or _stale(exe, [main, out] + hdrs):
+                _run_to(exe, ["g++"] + HOST_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + d],
+                        [main, "-L" + PKG, "-lrtgo_host", "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"], verbose)
     return out
 
 
