@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--mode", default="path", choices=["path", "distributed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-frame band gather (diagnostic)")
+    ap.add_argument("--launches-per-frame", type=int, default=0, choices=[0, 1, 2],
+                    help="a rank renders its share as 1 launch, or as 2 half-share launches on two contexts / HIP streams so that "
+                         "the tail and launch latency of one overlap the body of the other (0 = 2 when N >= 4, else 1)")
     ap.add_argument("--single-rank-collectives", action="store_true",
                     help="developer check on a 1-GPU box: run the N>1 machinery (RCCL process group, comm stream, triple-buffered "
                          "bands, gather + de-interleave every frame) with a world of one rank. The JSON line is marked.")
@@ -154,55 +157,73 @@ def main():
     path = args.mode == "path"
     band_h = 4
     t = hscene.tables(args.scene, W, H)          # C++ host (engine::host::Scene) -> flattened tables
-    ctx = capi.Context(local_rank)
-    ctx.set_scene(t["type"], t["M"], t["mat"], t["aabb"])
-    ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
-    ctx.set_background(t["bg"])
-    ctx.set_lights(t["lights"])
+    # S launches per frame and rank: the rank's share is cut into S sub-shares (virtual ranks v = rank*S + i of V = world*S in the
+    # band interleave), each with its own context and HIP stream.  A short launch ends with a tail in which few waves are still
+    # busy, and starts with ~13 us of launch latency; with two launches in flight one's tail and start overlap the other's body
+    # (a 1/8 share of the 1080p frame: 0.220 ms as one launch, 0.199 ms as two; a whole frame: 1.227 vs 1.243 -- hence N >= 4).
+    S = args.launches_per_frame if args.launches_per_frame else (2 if world >= 4 else 1)
+    V = world * S
+    ctxs = []
+    for i in range(S):
+        c = capi.Context(local_rank)
+        c.set_scene(t["type"], t["M"], t["mat"], t["aabb"])
+        c.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
+        c.set_background(t["bg"])
+        c.set_lights(t["lights"])
+        ctxs.append(c)
+    ctx = ctxs[0]
 
-    rows = capi.local_rows(H, band_h, world, rank)
-    rows_pad = bands.max_local_rows(H, band_h, world)
-    accum = torch.zeros((rows_pad, W, 4), dtype=torch.float32, device=dev)
-    image = torch.zeros((rows_pad, W, 4), dtype=torch.uint8, device=dev)
-    scratch_a = torch.zeros_like(accum)
-    scratch_i = torch.zeros_like(image)
-    # one explicit (non-default) HIP stream carries the megakernel AND everything torch enqueues (the RCCL gather waits
-    # on it), so kernel -> gather ordering is by stream; the ABI treats a NULL stream as "use the context's own"
-    stream = torch.cuda.Stream(dev)
+    rows_pad = bands.max_local_rows(H, band_h, V)      # rows of one sub-share, padded to the largest
+    sub_px = rows_pad * W
+    accum = torch.zeros((S * rows_pad, W, 4), dtype=torch.float32, device=dev)
+    image = torch.zeros((S * rows_pad, W, 4), dtype=torch.uint8, device=dev)
+    scratch_a = torch.zeros((max(S * rows_pad, H), W, 4), dtype=torch.float32, device=dev)
+    scratch_i = torch.zeros((max(S * rows_pad, H), W, 4), dtype=torch.uint8, device=dev)
+    # explicit (non-default) HIP streams carry the megakernels AND everything torch enqueues (the RCCL gather waits on
+    # them), so kernel -> gather ordering is by stream; the ABI treats a NULL stream as "use the context's own"
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    stream = streams[0]
     torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
+    for c, st_ in zip(ctxs, streams):
+        assert st_.cuda_stream != 0
+        c.set_stream(st_.cuda_stream)
     full_image = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    row_index = bands.full_row_index(H, band_h, world, rows_pad, dev) if (rank == 0 and multi) else None
+    row_index = bands.full_row_index(H, band_h, V, rows_pad, dev) if (rank == 0 and multi) else None
+    row_index_host = bands.full_row_index(H, band_h, V, rows_pad) if (rank == 0 and rehearse) else None
 
-    def frame(f, stats=False):
+    def frame(f, i=0, stats=False):
         # N > 1: leave 8 CUs' worth of workgroup slots free so that RCCL's kernels can run beside the persistent megakernel
-        return capi.make_frame(W, H, N, f, path, False, None, (band_h, world, rank), stats=stats,
+        return capi.make_frame(W, H, N, f, path, False, None, (band_h, V, rank * S + i), stats=stats,
                                reserve_cus=(8 if multi and not stats else 0))
 
+    def bind(i, acc_t, img_t):
+        ctxs[i].bind_output(acc_t.data_ptr() + i * sub_px * 16, img_t.data_ptr() + i * sub_px * 4, sub_px)
+
     # N > 1: the 8-bit bands are triple-buffered so that the gather of frame f (comm stream -> RCCL) overlaps the
-    # megakernel of frame f+1 (compute stream).  Every frame is still gathered and de-interleaved on rank 0 inside the
+    # megakernels of frame f+1 (compute streams).  Every frame is still gathered and de-interleaved on rank 0 inside the
     # timed region; the accumulation buffer is single (frame f+1 reads what frame f wrote, same stream).
     NBUF = 3
     images = [image] + [torch.zeros_like(image) for _ in range(NBUF - 1)] if multi else [image]
     comm = torch.cuda.Stream(dev, priority=-1) if multi else None
     gathered = [None] * NBUF   # event: the gather that last read images[b] has completed
-    gather_ws = (torch.empty((world * rows_pad, W, 4), dtype=torch.uint8, device=dev) if (multi and rank == 0) else None)
+    gather_ws = (torch.empty((world * S * rows_pad, W, 4), dtype=torch.uint8, device=dev) if (multi and rank == 0) else None)
 
     def step(f):
         b = f % NBUF if multi else 0
-        if multi and gathered[b] is not None:
-            stream.wait_event(gathered[b])            # WAR: do not overwrite a band buffer a gather is still reading
-        ctx.bind_output(accum.data_ptr(), images[b].data_ptr(), rows_pad * W)
-        ctx.launch(frame(f))
+        for i in range(S):
+            if multi and gathered[b] is not None:
+                streams[i].wait_event(gathered[b])        # WAR: do not overwrite a band buffer a gather is still reading
+            bind(i, accum, images[b])
+            ctxs[i].launch(frame(f, i))
         if multi and not args.no_gather:
-            done = torch.cuda.Event()
-            done.record(stream)
-            comm.wait_event(done)
+            for i in range(S):
+                done = torch.cuda.Event()
+                done.record(streams[i])
+                comm.wait_event(done)
             with torch.cuda.stream(comm):
                 if rehearse:
                     comm.synchronize()
-                    full = bands.gather_bands(images[b].cpu(), H, band_h, dist, dst=0)
+                    full = bands.gather_bands(images[b].cpu(), H, band_h, dist, dst=0, row_index=row_index_host)
                     if rank == 0:
                         full_image.copy_(full)
                 else:
@@ -217,12 +238,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def stats_sum():
+        tot = None
+        for c in ctxs:
+            st_ = c.stats()
+            if tot is None:
+                tot = dict(st_)
+            else:
+                for k in ("rays_total", "rays_occlusion", "node_visits", "prim_tests", "hits", "rays_culled", "total_launch_ms", "launches"):
+                    tot[k] += st_[k]
+        return tot
+
     # ---- V, T, h of the workload (instrumented kernel, untimed, into scratch buffers so the accumulation is untouched)
-    ctx.bind_output(scratch_a.data_ptr(), scratch_i.data_ptr(), rows_pad * W)
-    ctx.reset_stats()
-    ctx.launch(frame(args.warmup, stats=True))
-    ctx.sync()
-    st = ctx.stats()
+    for i in range(S):
+        bind(i, scratch_a, scratch_i)
+        ctxs[i].reset_stats()
+        ctxs[i].launch(frame(args.warmup, i, stats=True))
+    for c in ctxs:
+        c.sync()
+    st = stats_sum()
     rdev = torch.device("cpu") if rehearse else dev   # gloo reduces host tensors
     cnt = torch.tensor([st["rays_total"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=rdev)
     if multi:
@@ -233,21 +267,23 @@ def main():
     A_px = 36                                             # frame > 0: float4 read + float4 write + uchar4 write
 
     # ---- warmup + timed region
-    ctx.bind_output(accum.data_ptr(), image.data_ptr(), rows_pad * W)
     for f in range(args.warmup):
         step(f)
     sync_all()
-    ctx.reset_stats()
+    for c in ctxs:
+        c.reset_stats()
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
     sync_all()
     dt = time.perf_counter() - t0
-    st = ctx.stats()
+    st = stats_sum()
     tt = torch.tensor([dt], dtype=torch.float64, device=rdev)
     rr = torch.tensor([float(st["rays_total"]), float(st["rays_culled"])], dtype=torch.float64, device=rdev)
-    km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1)], dtype=torch.float64, device=rdev)
+    # S == 1: the megakernel's average duration by HIP events.  S == 2: the two launches of a frame overlap, so their event
+    # durations do too; the rank's kernel time per frame is then its wall time per frame
+    km = torch.tensor([float(st["total_launch_ms"]) / max(st["launches"], 1) if S == 1 else dt / args.steps * 1e3], dtype=torch.float64, device=rdev)
     if multi:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
@@ -271,6 +307,7 @@ def main():
             "config": {"workload": "%s %dx%d --mode=%s --sample=%d (%d spp), progressive frames %d..%d" %
                                    (args.scene, W, H, args.mode, N, N * N, args.warmup, args.warmup + args.steps - 1),
                        "primitives": int(len(t["type"])), "tiling": "4-row bands interleaved over %d GPU(s)" % world,
+                       "launches_per_frame_per_gpu": S,
                        "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (multi and not args.no_gather) else "none",
                        "rays_per_frame": int(round(rays_per_launch)),
                        # primary rays of pixels outside the screen rectangle of the scene's bounds: counted (the reference traces
@@ -283,7 +320,10 @@ def main():
                          "traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE+WRITE_SIZE)*1024",
                          "traffic_source": (traffic[1] if traffic and world == 1 else None),
                          "kernel": "rtgo::render_kernel<%s,false>" % ("true" if path else "false"),
-                         "kernel_ms": round(kernel_ms, 4), "A_ray_bytes": round(A_ray, 1), "A_px_bytes": A_px,
+                         "kernel_ms": round(kernel_ms, 4),
+                         "kernel_ms_basis": ("HIP events around each launch, averaged (slowest rank)" if S == 1 else
+                                             "wall time per frame of the slowest rank: its two launches per frame overlap, and so do their event durations"),
+                         "A_ray_bytes": round(A_ray, 1), "A_px_bytes": A_px,
                          "V": round(Vbar, 3), "T": round(Tbar, 3), "h": round(hbar, 4),
                          "achieved_min": round((rays_per_launch * 168 + W * H * A_px) / world / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0,
                          "mrays_roofline": round(HBM_PEAK_GBS * 1e3 / A_ray, 1),
@@ -293,21 +333,21 @@ def main():
         }
         if args.single_rank_collectives:
             out["single_rank_collectives"] = "N>1 machinery with a world of one rank (developer check): NOT the N=1 measurement"
-            out["gathered_frame_matches_local_image"] = bool(torch.equal(full_image, images[(args.warmup + args.steps - 1) % NBUF][:H]))
         if rehearse:
             out["rehearsal"] = "all ranks on cuda:0, gloo gather through host memory: NOT a measurement"
-            # correctness of the N>1 path: the gathered 8-bit frame must equal a whole-image render of the same frame
+        if rehearse or args.single_rank_collectives:
+            # correctness of the N>1 path: the gathered 8-bit frame must equal a whole-image render of the same frames
             whole_a = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
             whole_i = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev)
             ctx.bind_output(whole_a.data_ptr(), whole_i.data_ptr(), H * W)
             for f in range(args.warmup + args.steps):
                 ctx.launch(capi.make_frame(W, H, N, f, path, False, None, (band_h, 1, 0)))
             ctx.sync()
-            out["rehearsal_frame_matches_single_gpu"] = bool(torch.equal(whole_i, full_image))
+            out["gathered_frame_matches_single_launch"] = bool(torch.equal(whole_i, full_image))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_acc, ref_win = cpu_baseline(args.scene, W, H, N, path)
             # the same frame 0 on the GPU (untimed, scratch buffers), held against what the oracle just rendered
-            ctx.bind_output(scratch_a.data_ptr(), scratch_i.data_ptr(), rows_pad * W)
+            ctx.bind_output(scratch_a.data_ptr(), scratch_i.data_ptr(), H * W)
             ctx.launch(capi.make_frame(W, H, N, 0, path, False, None, (band_h, 1, 0)))
             ctx.sync()
             out["cpu_baseline"]["gpu_frame0_vs_oracle"] = parity_against(ref_acc, ref_win, scratch_a[:H].cpu().numpy())

@@ -585,7 +585,7 @@ def test_bench_contract_and_rccl_path_on_one_gpu():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--width", "320", "--height", "180", "--no-cpu-baseline"]
-    for extra in ([], ["--single-rank-collectives"]):
+    for extra in ([], ["--single-rank-collectives"], ["--single-rank-collectives", "--launches-per-frame", "2"]):
         r = subprocess.run(base + extra, capture_output=True, text=True, timeout=300, cwd=root)
         assert r.returncode == 0, r.stderr[-2000:]
         lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -596,4 +596,5 @@ def test_bench_contract_and_rccl_path_on_one_gpu():
             assert k in j, k
         assert j["n_gpus"] == 1 and j["steps"] == 4 and j["value"] > 0 and j["roofline"]["frac"] > 0
         if extra:
-            assert j["gathered_frame_matches_local_image"] is True
+            assert j["gathered_frame_matches_single_launch"] is True
+            assert j["config"]["launches_per_frame_per_gpu"] == (2 if len(extra) > 1 else 1)
