@@ -329,6 +329,11 @@ def main():
                          "mrays_roofline": round(HBM_PEAK_GBS * 1e3 / A_ray, 1),
                          # what actually binds the kernel (PMC of the committed profile): vector issue slots filled, lanes live in them
                          "secondary": ({"bound": "valu issue", **traffic[2]} if traffic and world == 1 and traffic[2] else None),
+                         # SURVEY 8d's second bound, on the same algorithmic counts: ~40 flop per node visit, ~100 per primitive test,
+                         # ~250 per shaded hit, against the 157.3 TFLOP/s f32 vector peak (MI355X_MICROARCH.md, peak table)
+                         "fp32_algorithmic": {"tflops": round(rays_per_launch * (40 * Vbar + 100 * Tbar + 250 * hbar) / world / (kernel_ms * 1e-3) / 1e12, 2) if kernel_ms > 0 else 0.0,
+                                              "peak_tflops": 157.3,
+                                              "flop_per_ray": round(40 * Vbar + 100 * Tbar + 250 * hbar, 1)},
                          "note": "algorithmic bytes (SURVEY 8d) per launch / HIP-event kernel time; the scene is LDS-resident so physical HBM traffic is only the framebuffer"},
         }
         if args.single_rank_collectives:
