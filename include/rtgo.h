@@ -121,6 +121,8 @@ int rtgo_set_stream(rtgo_ctx* ctx, void* hip_stream);
 /* Renderer::CreateShapes (renderer.cpp:400-453) = optixAccelBuild over n custom-primitive AABBs (:514-611) + the
    hit-group SBT upload (:636-653).  prims[i] is SBT index i (scene shape order, then primitive order).
    aabbs may be NULL: the boxes are then derived on the device with the CubeBox rule of primitive.cpp:35-79.
+   Boxes must contain their primitives (the reference's always do: CubeBox bounds the unit cube's image, padded); the timed
+   kernel relies on that and culls with its own tighter per-shape boxes.
    Builds M^-1 per primitive and the canonical LBVH on the device.  Synchronous. */
 int rtgo_set_scene(rtgo_ctx* ctx, const rtgo_prim* prims, const rtgo_aabb* aabbs, uint32_t n);
 
