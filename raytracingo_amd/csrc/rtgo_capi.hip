@@ -450,7 +450,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         p.bg_pixel = v3{sx * inv, sy * inv, sz * inv};
     }
     uint32_t wx0 = 0, wx1 = p.w, wy0 = 0, wy1 = p.h;
-    if (!stats) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);   // the instrumented kernel traces every pixel
+    if (!stats && !std::getenv("RTGO_NO_CULL")) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);   // the instrumented kernel traces every pixel
     const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
     const uint64_t units_hot = (uint64_t)((wx1 - wx0 + unit_px - 1) / unit_px) * (lr1 - lr0);
     {

@@ -1355,10 +1355,16 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         }
     };
     // 30-bit Morton code of primitive i's box centre normalised to the bounds in s_red[..][0]
-    auto morton_of = [&]() -> unsigned int {
+    auto morton_of = [&](int first = -1, int count = 1) -> unsigned int {   // centre of the union of the boxes [first, first + count)
+        if (first < 0) first = i;
         unsigned int q[3];
         for (int a = 0; a < 3; ++a) {
-            const float c = (s_box[i][a] + s_box[i][3 + a]) * 0.5f;
+            float lo = s_box[first][a], hi = s_box[first][3 + a];
+            for (int k = 1; k < count; ++k) {
+                lo = fminf(lo, s_box[first + k][a]);
+                hi = fmaxf(hi, s_box[first + k][3 + a]);
+            }
+            const float c = (lo + hi) * 0.5f;
             const float ext = s_red[3 + a][0] - s_red[a][0];
             const float u = ext > 0.0f ? (c - s_red[a][0]) / ext : 0.0f;
             q[a] = (unsigned int)fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
@@ -1500,19 +1506,22 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
 
     // ================= fast walk's structure =================
     // Any conservative structure returns the same closest hit, so this one is built for speed:
-    //  * TIGHT per-shape boxes (the reference's CubeBox boxes are up to 2x oversize per axis);
+    //  * TIGHT per-shape boxes for rectangles and disks (the reference's CubeBox boxes span a whole cube around a flat shape);
     //  * "big" primitives (box spanning >= 40 % of the scene on two axes: room walls, floors) stay out of the tree and are
     //    tested first, which also gives every ray an early closest-hit bound for culling the tree;
     //  * LBVH over the rest, subtrees collapsed into multi-primitive leaves by a cost budget.
-    if (i < n) {
+    // Spheres and cylinders keep the box the canonical walk uses (the caller's / the CubeBox one): their quadratic loses its
+    // digits with distance (b*b - 4ac at |o| ~ 2000 radii is good to ~0.1 radius), so from far away the intersection program
+    // reports hits up to tenths of a unit OFF the surface -- inside the reference's loose box, outside a tight one -- and the
+    // closest hit must be the reference's arithmetic, not the geometry (tools/fuzz_cameras.py found it: a camera 1200 units
+    // from the slide scene).  Rectangles and disks divide once (error ~1e-7 of the distance): their tight boxes stand.
+    if (i < n && (P.type == 2 || P.type == 1)) {
         const float* M = P.M;
         for (int a = 0; a < 3; ++a) {
-            const float mx = M[4 * a + 0], my = M[4 * a + 1], mz = M[4 * a + 2], c = M[4 * a + 3];
+            const float mx = M[4 * a + 0], mz = M[4 * a + 2], c = M[4 * a + 3];
             float e;  // half extent of the unit shape's image along world axis a
             if (P.type == 2) e = 0.5f * fabsf(mx) + 0.5f * fabsf(mz);   // rectangle |x|,|z| <= 1/2, y = 0
-            else if (P.type == 3) e = sqrtf(mx * mx + my * my + mz * mz);  // sphere
-            else if (P.type == 1) e = sqrtf(mx * mx + mz * mz);            // disk, radius 1 in y = 0
-            else e = sqrtf(mx * mx + mz * mz) + fabsf(my);                 // cylinder, radius 1, |y| <= 1
+            else e = sqrtf(mx * mx + mz * mz);                          // disk, radius 1 in y = 0
             e = e * 1.00001f + 0.001f;  // rounding headroom + the reference's own pad (AABB_EPSILON)
             s_box[i][a] = c - e;
             s_box[i][3 + a] = c + e;
@@ -1533,8 +1542,50 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     __syncthreads();
     const int n_small = s_count;
     reduce_bounds(i < n && !big);
+    // Boxes: six consecutive small rectangles that pair up by opposite normals (ShapeFactory::CreateCube emits a cube's faces
+    // consecutively, shapefactory.cpp) share ONE Morton code, that of the box centre, so that the Karras hierarchy keeps them
+    // in one subtree and the cost budget (6) turns exactly that subtree into a leaf: whole-box leaves, which pair_test halves.
+    // Left to the face centroids, Morton order cuts across touching boxes (checkered: leaves of every mix of pairs and singles).
+    if (i < n) s_used[i] = 0xFF;   // first primitive of the box this one belongs to, relative: 0..5, or 0xFF
+    __syncthreads();
+    if (i == 0) {
+        int a = 0;
+        while (a + 6 <= n) {
+            bool ok = true;
+            for (int k = 0; k < 6 && ok; ++k) ok = prims[a + k].type == 2u && !s_flag[a + k];
+            if (ok) {
+                unsigned int paired = 0;
+                for (int k = 0; k < 6; ++k) {
+                    if (paired & (1u << k)) continue;
+                    const float4 ra = out_prims[6 * (a + k) + 1];
+                    const float la = sqrtf(ra.x * ra.x + ra.y * ra.y + ra.z * ra.z);
+                    for (int m = k + 1; m < 6; ++m) {
+                        if (paired & (1u << m)) continue;
+                        const float4 rb = out_prims[6 * (a + m) + 1];
+                        const float lb = sqrtf(rb.x * rb.x + rb.y * rb.y + rb.z * rb.z);
+                        if (ra.x * rb.x + ra.y * rb.y + ra.z * rb.z < -0.9999f * la * lb) {
+                            paired |= (1u << k) | (1u << m);
+                            break;
+                        }
+                    }
+                }
+                ok = paired == 0x3Fu;
+            }
+            if (ok) {
+                for (int k = 0; k < 6; ++k) s_used[a + k] = (unsigned char)k;
+                a += 6;
+            } else {
+                a += 1;
+            }
+        }
+    }
+    __syncthreads();
     // small primitives sort by Morton code; big ones after them, in SBT order
-    s_keys[i] = (i < n) ? ((big ? (0xFFFFFFFEull << 32) : ((unsigned long long)morton_of() << 32)) | (unsigned int)i) : ~0ull;
+    {
+        const bool boxed = i < n && s_used[i] != 0xFF;
+        const unsigned int code = (i < n && !big) ? (boxed ? morton_of(i - (int)s_used[i], 6) : morton_of()) : 0u;
+        s_keys[i] = (i < n) ? ((big ? (0xFFFFFFFEull << 32) : ((unsigned long long)code << 32)) | (unsigned int)i) : ~0ull;
+    }
     sort_keys();
     if (i < n_small) {
         const int prim = (int)(s_keys[i] & 0xFFFFFFFFu);
