@@ -4,6 +4,7 @@
 #include "../../include/rtgo.h"
 #include "rtgo_device.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -451,6 +452,17 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     uint32_t wx0 = 0, wx1 = p.w, wy0 = 0, wy1 = p.h;
     if (!stats && !std::getenv("RTGO_NO_CULL")) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);   // the instrumented kernel traces every pixel
+    // The fast walk's tight boxes carry 1e-3 of padding against the rounding of the intersection programs, which grows with
+    // the coordinates involved (~1e-7 of them for a rectangle's hit point).  Beyond 500 units -- the reference's scenes stay
+    // within 20, its camera at 14 -- the launch takes the canonical walk instead: slower, and equal to it by definition.
+    bool canon = stats;
+    {
+        float reach = 0.0f;
+        for (int k = 0; k < 6; ++k) reach = std::fabs(c->bounds[k]) > reach ? std::fabs(c->bounds[k]) : reach;
+        const float e[3] = {p.eye.x, p.eye.y, p.eye.z};
+        for (int k = 0; k < 3; ++k) reach = std::fabs(e[k]) > reach ? std::fabs(e[k]) : reach;
+        if (!(reach <= 500.0f)) canon = true;
+    }
     const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
     const uint64_t units_hot = (uint64_t)((wx1 - wx0 + unit_px - 1) / unit_px) * (lr1 - lr0);
     {
@@ -489,7 +501,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.fprims = c->d_fprims;
     p.n_small = c->n_small;
     p.n_big_pairs = c->n_big_pairs;
-    p.stack_depth = stats ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
+    p.stack_depth = canon ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
     p.lights = c->d_lights;
     p.accum = c->d_accum;
     p.image = c->d_image;
@@ -513,7 +525,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // The scene copy is per workgroup and the stack per lane, so bigger scenes want bigger workgroups: pick the size that
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
     const int fast_nodes = c->n_small > 0 ? 2 * c->n_small - 1 : 0;
-    const size_t scene_lds = (size_t)(2 * (stats ? p.n_nodes : fast_nodes) + (stats ? 6 : 7) * p.n_prims) * sizeof(float4) +
+    const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims) * sizeof(float4) +
                              (size_t)kMaxLights * sizeof(LightRec);
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
     size_t lds = 0;
@@ -523,7 +535,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // of fewer waves wins (a 1/16 share: 0.127 / 0.137 / 0.162 ms at 4 / 5 / 6).
     const uint64_t units_per_wave4 = units_hot * (passes_of(nn)) / ((uint64_t)c->num_cus * 16u);
     const int max_wpe_work = units_per_wave4 >= 12 ? 6 : (units_per_wave4 >= 3 ? 5 : 4);
-    const int max_wpe = stats ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);
+    const int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);
     for (int w = 4; w <= max_wpe; ++w)
         for (int b = 256; b <= kMaxBlock; b *= 2) {
             const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2) + (w >= 5 ? (size_t)b * 4 * kMaxLevels * sizeof(float) : 0);
@@ -559,8 +571,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const float4* fp = (const float4*)c->d_fprims;
-    if (path && stats) hipLaunchKernelGGL((render_kernel<true, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (!path && stats) hipLaunchKernelGGL((render_kernel<false, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    if (path && canon) hipLaunchKernelGGL((render_kernel<true, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    else if (!path && canon) hipLaunchKernelGGL((render_kernel<false, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (path && wpe == 6) hipLaunchKernelGGL((render_kernel<true, false, 6>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (path && wpe == 5) hipLaunchKernelGGL((render_kernel<true, false, 5>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (path) hipLaunchKernelGGL((render_kernel<true, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
