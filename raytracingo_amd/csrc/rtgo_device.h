@@ -478,7 +478,7 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
 // and d.y is the ray direction against the world normal, so at most one of the two can get past that first test -- the
 // rest of the test then runs once, on whichever it is, instead of twice with half of the lanes masked off.  Exactly the
 // tests leaf_test() would make, on the same values: when rounding lets BOTH through, both are tested.
-template <typename Ptr>
+template <bool LIST, typename Ptr>
 __device__ __forceinline__ void pair_test(Ptr fp, const float4* __restrict__ lds, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
 {
     // fp: where the two normals come from (the up-front list reads them through scalar loads); lds: the LDS copy of the same
@@ -495,7 +495,8 @@ __device__ __forceinline__ void pair_test(Ptr fp, const float4* __restrict__ lds
     }
     if (fa || fb) {
         const int sel = fa ? pos : pos + 1;
-        const float4 r1 = lds[4 * sel + 1];
+        // (rows already in VGPRs are chosen by four selects; rows in SGPRs would take twelve instructions: re-read the row instead)
+        const float4 r1 = LIST ? lds[4 * sel + 1] : make_float4(fa ? r1a.x : r1b.x, fa ? r1a.y : r1b.y, fa ? r1a.z : r1b.z, fa ? r1a.w : r1b.w);
         const float dy = fa ? dya : dyb;
         const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
         if (oy > 0.0f) {
@@ -523,7 +524,7 @@ template <bool LIST, typename Ptr>
 __device__ __forceinline__ void leaf_range(Ptr fp, const float4* __restrict__ lds, int first, int cnt, int npairs, v3 wo, v3 wd, float tmin, FastHit& best)
 {
 #pragma unroll 1
-    for (int k = 0; k < npairs; ++k) pair_test(fp, lds, first + 2 * k, wo, wd, tmin, best);
+    for (int k = 0; k < npairs; ++k) pair_test<LIST>(fp, lds, first + 2 * k, wo, wd, tmin, best);
     if (LIST) {
 #pragma unroll 2
         for (int k = 2 * npairs; k < cnt; ++k) leaf_test(fp, first + k, wo, wd, tmin, best);
