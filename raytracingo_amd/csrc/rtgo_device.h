@@ -702,6 +702,20 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
     return ray;
 }
 
+// `dot(N, normalize(w)) < 0` (kernel.cu:437-441: V = normalize(ray.origin - x); if (dot(N, V) < 0) N = -N) without the
+// normalisation when the sign is beyond doubt.  V_i = fl(w_i * inv) with inv > 0 carries one rounding, each product and each of
+// the two additions one more: the computed dot differs from dot(N, w) * inv by less than 5e-7 of sum |N_i w_i| * inv, so
+// beyond 1e-6 of that sum its sign is the sign of dot(N, w).  Closer calls (grazing within a microradian, NaN, w = 0) are
+// decided by the reference's own expression.  (Saves a sqrt and a division per hit.)
+__device__ __forceinline__ bool faces_away(v3 N, v3 w)
+{
+    const float ax = N.x * w.x, ay = N.y * w.y, az = N.z * w.z;
+    const float s = ax + ay + az;
+    const float sa = fabsf(ax) + fabsf(ay) + fabsf(az);
+    if (fabsf(s) > 1e-6f * sa) return s < 0.0f;
+    return vdot(N, vnormalize(w)) < 0.0f;
+}
+
 __device__ __forceinline__ float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }  // vec_math.h:115-118
 
 __device__ __forceinline__ unsigned int wave_sum(unsigned int v)
@@ -958,7 +972,6 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         v3 sN = mk(0, 0, 0), sRr = mk(0, 0, 0);
         float sDist = 0.0f;
         int sPrim = 0, sLight = 0;
-        bool sNVneg = false;
 
 #ifdef RTGO_TIMELINE
         if (tl_units++ == 0) tl_first = wall_clock64();
@@ -1001,8 +1014,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         const float t = h.t;
                         const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
                         const v3 x = vadd(ro, vscale(vnormalize(rd), t));
-                        const v3 V = vnormalize(vsub(ro, x));
-                        if (vdot(N, V) < 0.0f) N = vscale(N, -1.0f);
+                        if (faces_away(N, vsub(ro, x))) N = vscale(N, -1.0f);
                         if (m5.x > 0.01f) {
                             term = mk(m5.x, m5.y, m5.z);
                             done = true;
@@ -1046,7 +1058,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         const v3 lightColor = vscale(illum, fabsf(vdot(Lm, lightNormal)));
                         const float falloff = 1.0f / (1.0f + L.falloff * sDist);
                         const v3 compDiffuse =
-                            sNVneg ? mk(0.0f, 0.0f, 0.0f) : vmul(vscale(lightColor, fmaxf(vdot(sN, Lm), 0.0f)), kd);
+                            vmul(vscale(lightColor, fmaxf(vdot(sN, Lm), 0.0f)), kd);   // (kernel.cu:503 tests dot(N, V) < 0 again: after the flip it never is)
                         const v3 a = vadd(mk(0.0f, 0.0f, 0.0f), vscale(compDiffuse, falloff));
                         bool bounce = false;
                         v3 r = mk(0, 0, 0);
@@ -1095,8 +1107,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
                         const v3 dn = vnormalize(rd);
                         const v3 x = vadd(ro, vscale(dn, t));
-                        const v3 V = vnormalize(vsub(ro, x));
-                        if (vdot(N, V) < 0.0f) N = vscale(N, -1.0f);
+                        if (faces_away(N, vsub(ro, x))) N = vscale(N, -1.0f);
                         if (vlength(mk(m5.x, m5.y, m5.z)) > 0.01f) {
                             term = mk(1.0f, 1.0f, 1.0f);
                             done = true;
@@ -1114,7 +1125,6 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                             const v3 omega = vneg(dn);
                             sRr = vadd(vneg(omega), vscale(N, 2.0f * vdot(N, omega)));
                             sN = N;
-                            sNVneg = vdot(N, V) < 0.f;
                             sDist = lightDistance;
                             sPrim = h.prim;
                             sLight = l;
