@@ -806,6 +806,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     // small scenes (the 5-waves-per-SIMD variant): per-level path records live in LDS, [4 words x kMaxLevels][lane], instead of
     // 15-20 VGPRs -- that is what lets the allocation fit 96 registers without spilling to scratch
     constexpr bool LVLDS = (WPE >= 5);
+    constexpr int LVW = PATH ? 3 : 4;   // words per level record: the weight (path) / the term and the primitive (distributed)
     float* s_lv = reinterpret_cast<float*>(s_lights + kMaxLights) + threadIdx.x;
 
     const int tid = threadIdx.x;
@@ -1022,9 +1023,9 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                             const v3 Ra = hemisphere(N, N, 0.0f, seed);
                             const v3 wk = vadd(mk(0.0f, 0.0f, 0.0f), vscale(mk(m3.x, m3.y, m3.z), vdot(N, Ra)));
                             if constexpr (LVLDS) {
-                                s_lv[(depth * 4 + 0) << bshift] = wk.x;
-                                s_lv[(depth * 4 + 1) << bshift] = wk.y;
-                                s_lv[(depth * 4 + 2) << bshift] = wk.z;
+                                s_lv[(depth * LVW + 0) << bshift] = wk.x;
+                                s_lv[(depth * LVW + 1) << bshift] = wk.y;
+                                s_lv[(depth * LVW + 2) << bshift] = wk.z;
                             } else {
 #pragma unroll
                                 for (int k = 0; k < kMaxLevels; ++k)
@@ -1075,10 +1076,10 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         }
                         if (bounce) {
                             if constexpr (LVLDS) {
-                                s_lv[(depth * 4 + 0) << bshift] = a.x;
-                                s_lv[(depth * 4 + 1) << bshift] = a.y;
-                                s_lv[(depth * 4 + 2) << bshift] = a.z;
-                                s_lv[(depth * 4 + 3) << bshift] = __int_as_float(sPrim);
+                                s_lv[(depth * LVW + 0) << bshift] = a.x;
+                                s_lv[(depth * LVW + 1) << bshift] = a.y;
+                                s_lv[(depth * LVW + 2) << bshift] = a.z;
+                                s_lv[(depth * LVW + 3) << bshift] = __int_as_float(sPrim);
                             } else {
 #pragma unroll
                                 for (int k = 0; k < kMaxLevels; ++k)
@@ -1141,11 +1142,11 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                     // fold the level records innermost-first: kernel.cu:471-472 (path), :504,519,531 (distributed)
                     if constexpr (LVLDS) {
                         for (int k = depth - 1; k >= 0; --k) {
-                            const v3 a = mk(s_lv[(k * 4 + 0) << bshift], s_lv[(k * 4 + 1) << bshift], s_lv[(k * 4 + 2) << bshift]);
+                            const v3 a = mk(s_lv[(k * LVW + 0) << bshift], s_lv[(k * LVW + 1) << bshift], s_lv[(k * LVW + 2) << bshift]);
                             if (PATH) {
                                 term = vmul(a, term);
                             } else {
-                                const int prim = __float_as_int(s_lv[(k * 4 + 3) << bshift]);
+                                const int prim = __float_as_int(s_lv[(k * LVW + 3) << bshift]);
                                 const float4 m3 = s_mat[MS * prim + 0], m4 = s_mat[MS * prim + 1];
                                 term = vadd(a, vmul(mk(m4.x, m4.y, m4.z), term));
                                 if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
