@@ -1331,7 +1331,7 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
-                                                          float4* __restrict__ out_fprims, int leaf_budget, int* __restrict__ out_meta)
+                                                          float4* __restrict__ out_fprims, int leaf_budget, float big_frac, int* __restrict__ out_meta)
 {
     __shared__ float s_box[kMaxPrims][6];               // per primitive: reference AABB, later the tight box
     __shared__ unsigned long long s_keys[kMaxPrims];
@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     if (i < n) {
         int wide = 0;
         for (int a = 0; a < 3; ++a)
-            if (s_box[i][3 + a] - s_box[i][a] >= 0.4f * (s_red[3 + a][0] - s_red[a][0])) ++wide;
+            if (s_box[i][3 + a] - s_box[i][a] >= big_frac * (s_red[3 + a][0] - s_red[a][0])) ++wide;
         big = wide >= 2;
         s_flag[i] = big ? 1 : 0;
         if (!big) atomicAdd(&s_count, 1);
