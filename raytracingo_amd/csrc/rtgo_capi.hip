@@ -284,8 +284,24 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     if (!c || !prims) return fail(c, RTGO_E_INVALID, "rtgo_set_scene: NULL argument");
     if (n == 0 || n > RTGO_MAX_PRIMS)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: primitive count must be in [1, " + std::to_string(RTGO_MAX_PRIMS) + "]");
-    for (uint32_t i = 0; i < n; ++i)
-        if (prims[i].type > RTGO_SPHERE) return fail(c, RTGO_E_INVALID, "rtgo_set_scene: unknown primitive type");
+    for (uint32_t i = 0; i < n; ++i) {
+        const rtgo_prim& q = prims[i];
+        if (q.type > RTGO_SPHERE) return fail(c, RTGO_E_INVALID, "rtgo_set_scene: unknown primitive type");
+        // the intersection programs work in object space through M^-1 (kernel.cu:125-135): M must be finite and invertible
+        bool finite = std::isfinite(q.specularity);
+        for (int k = 0; k < 16; ++k) finite = finite && std::isfinite(q.model[k]);
+        for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(q.kd[k]) && std::isfinite(q.kr[k]) && std::isfinite(q.Le[k]);
+        const double a = q.model[0], b = q.model[1], d3 = q.model[2], e = q.model[4], g = q.model[5], h = q.model[6], k2 = q.model[8],
+                     l = q.model[9], m = q.model[10];
+        const double det = a * (g * m - h * l) - b * (e * m - h * k2) + d3 * (e * l - g * k2);
+        if (!finite || !std::isfinite(det) || std::fabs(det) < 1e-30)
+            return fail(c, RTGO_E_INVALID, "rtgo_set_scene: primitive " + std::to_string(i) + " has a non-finite or singular model matrix / material");
+        if (aabbs) {
+            const rtgo_aabb& bb = aabbs[i];
+            if (!(bb.minX <= bb.maxX && bb.minY <= bb.maxY && bb.minZ <= bb.maxZ) || !std::isfinite(bb.minX + bb.minY + bb.minZ + bb.maxX + bb.maxY + bb.maxZ))
+                return fail(c, RTGO_E_INVALID, "rtgo_set_scene: box " + std::to_string(i) + " is empty or not finite");
+        }
+    }
     RTGO_HIP(c, hipSetDevice(c->device));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(c->d_prims_in);

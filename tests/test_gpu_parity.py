@@ -171,6 +171,16 @@ def test_error_behaviour(capi, oracle):
         ctx2.launch(capi.make_frame(64, 64, window=(10, 10, 64, 64)))
     with pytest.raises(capi.RtgoError):
         ctx.set_scene(np.zeros(0, np.int32), np.zeros((0, 16), np.float32), np.zeros((0, 10), np.float32))
+    # a singular or non-finite model matrix has no object space to intersect in: refused, not rendered
+    ident = np.eye(4, dtype=np.float32).reshape(1, 16)
+    mat = np.array([[0.5, 0.5, 0.5, 0, 0, 0, 1, 0, 0, 0]], np.float32)
+    flat = ident.copy(); flat[0, 5] = 0.0
+    nan = ident.copy(); nan[0, 3] = np.nan
+    for M in (flat, nan):
+        with pytest.raises(capi.RtgoError):
+            ctx.set_scene(np.array([2], np.int32), M, mat)
+    with pytest.raises(capi.RtgoError):
+        ctx.set_scene(np.full(513, 3, np.int32), np.repeat(ident, 513, 0), np.repeat(mat, 513, 0))
 
 
 def test_config3_balls_1080p_properties(capi, oracle):
@@ -624,3 +634,50 @@ def test_far_camera_where_the_sphere_quadratic_loses_its_digits(capi, oracle):
             racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
             assert_parity(canon, racc, cimg, rimg, min_frac=0.99, what="far camera path=%s" % path)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_smallest_and_largest_scenes(capi, oracle):
+    """one primitive (no tree at all: the fast walk is its up-front list or a root leaf) and the maximum of 512 (every LDS array
+    of the build at its limit; workgroup size and stack chosen for it), both kernels against each other and the oracle"""
+    W, H, n = 80, 60, 2
+    L = oracle.lib()
+    cam = oracle.scene_tables(oracle.scene("cornell", W, H))["cam"]
+    rng = np.random.RandomState(7)
+
+    def trs(t, s):
+        T, S, out = [np.zeros(16, dtype=np.float32) for _ in range(3)]
+        L.oracle_mat_translate(*[np.float32(v) for v in t], oracle.fptr(T))
+        L.oracle_mat_scale(*[np.float32(v) for v in s], oracle.fptr(S))
+        L.oracle_mat_mul(oracle.fptr(T), oracle.fptr(S), oracle.fptr(out))
+        return out
+
+    light = trs((0, 6, 0), (8, 1, 8))
+    R = np.zeros(16, dtype=np.float32); out = np.zeros(16, dtype=np.float32)
+    L.oracle_mat_rotate(np.float32(np.pi), 1.0, 0.0, 0.0, oracle.fptr(R))
+    L.oracle_mat_mul(oracle.fptr(light), oracle.fptr(R), oracle.fptr(out))
+    light = out.copy()
+    cases = []
+    for ptype, m in ((3, trs((0, 0, 0), (3, 3, 3))), (2, trs((0, -1, 0), (9, 1, 9)))):
+        cases.append((np.array([ptype, 2]), np.stack([m, light]), np.array([[0.8, 0.3, 0.3, 0.2, 0.2, 0.2, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0, 1, 8, 8, 8]], np.float32)))
+    types = rng.randint(0, 4, 512); types[0] = 2
+    M = np.stack([light] + [trs(rng.uniform(-6, 6, 3), rng.uniform(0.15, 0.6, 3)) for _ in range(511)])
+    mats = np.zeros((512, 10), np.float32); mats[:, 0:3] = rng.uniform(0.2, 1, (512, 3)); mats[:, 6] = 1.0
+    mats[0] = [0, 0, 0, 0, 0, 0, 1, 8, 8, 8]
+    cases.append((types, M, mats))
+    for types, M, mats in cases:
+        sc = oracle.scene_from_tables(types, M, mats, np.stack([oracle.light_from_matrix(light, falloff=0.02)]), cam, (0.1, 0.1, 0.2))
+        t = oracle.scene_tables(sc)
+        ctx = capi.Context(0)
+        ctx.set_scene(t["type"], t["M"], t["mat"], None)
+        ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12]); ctx.set_background(t["bg"]); ctx.set_lights(t["lights"])
+        for path in (True, False):
+            ctx.reset_stats()
+            canon, cimg = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
+            st = ctx.stats()
+            fast, fimg = gpu_render(capi, ctx, W, H, n, 0, path)
+            assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), (len(types), path)
+            racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
+            assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="%d primitives path=%s" % (len(types), path))
+            assert abs(st["rays_total"] - rc["rays_total"]) <= 0.01 * rc["rays_total"]
+        ctx.close()
