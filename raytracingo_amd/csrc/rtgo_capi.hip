@@ -58,6 +58,9 @@ struct rtgo_ctx {
     int queue_set = 0;
     unsigned long long rays_culled = 0;       // since rtgo_reset_stats (host arithmetic: the cold pixels of each launch x N*N)
     unsigned long long* d_counters = nullptr;  // 8 x u64
+#ifdef RTGO_CMPWALK
+    float* d_cmp = nullptr;                    // diagnostic build: disagreements between the two walks
+#endif
 #ifdef RTGO_TIMELINE
     unsigned long long* d_timeline = nullptr;  // diagnostic build: 8 x u64 per wave
     unsigned int timeline_waves = 0;
@@ -162,6 +165,19 @@ static void scene_screen_rect(const rtgo_ctx* c, const LaunchParams& p, uint32_t
 }
 
 extern "C" {
+
+#ifdef RTGO_CMPWALK
+// diagnostic build only (tools/cmp_walks.py): rays on which the canonical and the fast walk disagreed since the last call
+extern "C" int rtgo_debug_cmpwalk(rtgo_ctx* c, void* host, size_t bytes)
+{
+    if (!c || !c->d_cmp) return -1;
+    if (rtgo_sync(c)) return -1;
+    const size_t n = 256 * 16 * sizeof(float);
+    if (hipMemcpy(host, c->d_cmp, n < bytes ? n : bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemset(c->d_cmp, 0, n) != hipSuccess) return -1;
+    return 0;
+}
+#endif
 
 #ifdef RTGO_TIMELINE
 // diagnostic build only (tools/timeline.py): per-wave records of the last launch; returns the number of waves
@@ -525,6 +541,13 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.queue = c->d_queue + (size_t)c->queue_set * kQueues * kQueueStride;
     p.queue_next = c->d_queue + (size_t)(1 - c->queue_set) * kQueues * kQueueStride;
     p.counters = c->d_counters;
+#ifdef RTGO_CMPWALK
+    if (!c->d_cmp) {
+        RTGO_HIP(c, hipMalloc(&c->d_cmp, 256 * 16 * sizeof(float)));
+        RTGO_HIP(c, hipMemset(c->d_cmp, 0, 256 * 16 * sizeof(float)));
+    }
+    p.cmp = c->d_cmp;
+#endif
 #ifdef RTGO_TIMELINE
     if (!c->d_timeline) RTGO_HIP(c, hipMalloc(&c->d_timeline, 16384 * 128));
     p.timeline = c->d_timeline;

@@ -77,6 +77,9 @@ struct LaunchParams {
 #ifdef RTGO_TIMELINE
     unsigned long long* timeline;    // diagnostic build: 8 words per wave, see tools/timeline.py
 #endif
+#ifdef RTGO_CMPWALK
+    float* cmp;                      // diagnostic build: [0] = number of rays on which the two walks disagree, then 16-float records
+#endif
     v3 eye, U, V, Wv, bg;
     v3 bg_pixel;                     // ((0 + bg) + bg + ... N*N times) * (1/(N*N)) in float: the value of a pixel whose samples all miss
 };
@@ -585,7 +588,13 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     const unsigned long long tl_s1 = wall_clock64() + (best.pos == 12345 ? 1 : 0);
     tl_big += tl_s1 - tl_s0;
 #endif
-    const v3 id = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    // 1/d for the slab tests.  A direction component that is exactly zero is not rare: the hemisphere sample has sin(phi) = 0
+    // whenever its random number is 0 (one ray in 2^24 per bounce, a few per 1080p frame), and cameras can be axis-aligned.
+    // rcp(0) = inf would turn fma(b, 1/d, -o/d) into inf - inf = NaN on one side of the origin and -inf on the other, and a
+    // box straddling zero would be dropped; a huge FINITE reciprocal keeps both products finite and the slab's sign logic
+    // intact (inside: (-huge, +huge); outside: both ends on one side).
+    auto safe_rcp = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : __builtin_amdgcn_rcpf(x); };
+    const v3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
     float tn;
     float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0;
@@ -1000,6 +1009,24 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                 );
                 if (STATS && hit) c_hits += 1;
                 any_hit = any_hit || hit;
+#ifdef RTGO_CMPWALK
+                if constexpr (STATS) {
+                    // diagnostic build (tools/cmp_walks.py): the fast walk on the same ray, straight from global memory
+                    Hit hf;
+                    unsigned int d0 = 0, d1 = 0;
+                    const bool hitf = closest_hit_fast(p.fnodes, p.fprims, p.fprims, s_stack, bshift, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, hf, d0, d1);
+                    const bool same = hit == hitf && (!hit || (h.t == hf.t && h.prim == hf.prim && h.n.x == hf.n.x && h.n.y == hf.n.y && h.n.z == hf.n.z));
+                    if (!same) {
+                        const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(p.cmp), 1u);
+                        if (slot < 255u) {
+                            float* r = p.cmp + 16 * (slot + 1);
+                            r[0] = ro.x; r[1] = ro.y; r[2] = ro.z; r[3] = rd.x; r[4] = rd.y; r[5] = rd.z; r[6] = tmin; r[7] = tmax;
+                            r[8] = hit ? h.t : -1.0f; r[9] = hit ? (float)h.prim : -1.0f; r[10] = hitf ? hf.t : -1.0f; r[11] = hitf ? (float)hf.prim : -1.0f;
+                            r[12] = (float)depth; r[13] = (float)phase; r[14] = 0.0f; r[15] = 0.0f;
+                        }
+                    }
+                }
+#endif
 
                 bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
                 v3 term = mk(0, 0, 0);

@@ -681,3 +681,29 @@ def test_smallest_and_largest_scenes(capi, oracle):
             assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="%d primitives path=%s" % (len(types), path))
             assert abs(st["rays_total"] - rc["rays_total"]) <= 0.01 * rc["rays_total"]
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "checkered", "window"])
+def test_rays_with_an_exactly_zero_direction_component(capi, oracle, name):
+    """A hemisphere sample has sin(phi) = 0 exactly whenever its random number is 0 (one bounce in 2^24: a few rays per 1080p
+    frame), and then one direction component is exactly zero; 1/0 in the fast walk's slab test once dropped every box that
+    straddles the origin on that axis (found by tools/fuzz_scenes.py, one pixel in 3e7).  Here every primary ray has it: a
+    camera whose three axes lie in a coordinate plane (the ABI takes any U, V, W)."""
+    W, H, n = 96, 64, 2
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    for axis in range(3):
+        a, b = [k for k in range(3) if k != axis]
+        eye = np.zeros(3, np.float32); eye[axis] = 0.3; eye[a] = 0.2; eye[b] = -0.4
+        U, V, Wv = [np.zeros(3, np.float32) for _ in range(3)]
+        U[a], V[b] = 1.0, 1.0
+        Wv[a], Wv[b] = 0.35, 0.15
+        sc.eye[:], sc.U[:], sc.V[:], sc.W[:] = eye.tolist(), U.tolist(), V.tolist(), Wv.tolist()
+        ctx.set_camera(eye, U, V, Wv)
+        for path in (True, False):
+            fast, fimg = gpu_render(capi, ctx, W, H, n, 0, path)
+            canon, cimg = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
+            assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), (name, axis, path)
+            racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
+            assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="%s zero component %d path=%s" % (name, axis, path))
+    ctx.close()
