@@ -13,7 +13,7 @@ tg = importlib.util.module_from_spec(spec); spec.loader.exec_module(tg)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 W, H = 96, 64
-bad = 0; launches = 0
+bad = 0; launches = 0; ray_bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     kind = seed % 3
@@ -52,5 +52,15 @@ for seed in range(first, first + count):
             bad += 1
             print("MISMATCH seed %d trial %d: kind %d n %d frame %d path %s amb %s md %d win %s bands %s eye %s: %d pixels" %
                   (seed, trial, kind, n, frame, path, amb, md, win, (G, g), eye, int((outs[0].view(np.uint32) != outs[1].view(np.uint32)).any(axis=-1).sum())))
+    if hasattr(ctx._lib, "rtgo_debug_cmpwalk"):   # -DRTGO_CMPWALK build: the instrumented launches compared the walks ray by ray
+        import ctypes as C
+        ctx._lib.rtgo_debug_cmpwalk.restype = C.c_int; ctx._lib.rtgo_debug_cmpwalk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        buf = np.zeros((256, 16), np.float32)
+        ctx._lib.rtgo_debug_cmpwalk(ctx._h, buf.ctypes.data, buf.nbytes)
+        k = int(buf[0].view(np.uint32)[0])
+        ray_bad += k
+        if k:
+            print("seed %d: %d rays on which the walks disagree; first: o %s d %s tmin %g tmax %g canonical (%g, %d) fast (%g, %d)" %
+                  (seed, k, buf[1, 0:3], buf[1, 3:6], buf[1, 6], buf[1, 7], buf[1, 8], int(buf[1, 9]), buf[1, 10], int(buf[1, 11])))
     ctx.close()
-print("%d scenes, %d launch pairs, %d mismatches" % (count, launches, bad))
+print("%d scenes, %d launch pairs, %d mismatches; rays on which the walks disagree (RTGO_CMPWALK build only): %d" % (count, launches, bad, ray_bad))
