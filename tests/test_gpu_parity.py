@@ -707,3 +707,23 @@ def test_rays_with_an_exactly_zero_direction_component(capi, oracle, name):
             racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
             assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="%s zero component %d path=%s" % (name, axis, path))
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_both_walks_agree_on_every_ray(tmp_path):
+    """the -DRTGO_CMPWALK build of the library runs the fast walk next to the canonical one on EVERY ray of an instrumented launch
+    and records the rays on which hit, t, primitive or normal differ (tools/cmp_walks.py): all 8 scenes x 3 modes, none"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from raytracingo_amd import _build
+    lib = str(tmp_path / "librtgo_hip_cmpwalk.so")
+    subprocess.check_call([_build.HIPCC] + _build.HIP_FLAGS + ["-DRTGO_CMPWALK", "-o", lib, os.path.join(root, "raytracingo_amd", "csrc", "rtgo_capi.hip")])
+    env = dict(os.environ, RTGO_HIP_LIB=lib)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "cmp_walks.py"), "480", "270", "3", "2"], capture_output=True, text=True,
+                       timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.splitlines() if l.startswith("total:")][-1]
+    rays, bad = int(last.split()[1]), int(last.split()[3])
+    assert rays > 100_000_000 and bad == 0, r.stdout[-3000:]
