@@ -569,13 +569,13 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
                              (size_t)kMaxLights * sizeof(LightRec);
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
     size_t lds = 0;
-    // Waves per SIMD the kernel variant is compiled for: 4 (<= 128 VGPRs), 5 (<= 96, level records in LDS), 6 (<= 80, some spills),
-    // 7 (<= 72, path mode only: its level records are three words).
-    // More resident waves fill more of the vector issue slots (cornell 1080p: 1.285 ms at 5, 1.235 at 6, +1 % more at 7), but every wave then
+    // Waves per SIMD the kernel variant is compiled for: 4 (<= 128 VGPRs), 5 (<= 96, level records in LDS), 6 (<= 80, some spills).
+    // (A 7-waves variant, <= 72 VGPRs, bought 0.8 % on cornell and doubled the spill traffic, 556 -> 1135 MB per launch: dropped.)
+    // More resident waves fill more of the vector issue slots (cornell 1080p: 1.285 ms at 5, 1.235 at 6), but every wave then
     // runs slower and the launch ends one unit-duration after the queue runs dry: with few units per wave the shorter tail
     // of fewer waves wins (a 1/16 share: 0.127 / 0.137 / 0.162 ms at 4 / 5 / 6).
     const uint64_t units_per_wave4 = units_hot * (passes_of(nn)) / ((uint64_t)c->num_cus * 16u);
-    const int max_wpe_work = (units_per_wave4 >= 24 && path) ? 7 : (units_per_wave4 >= 12 ? 6 : (units_per_wave4 >= 3 ? 5 : 4));
+    const int max_wpe_work = units_per_wave4 >= 12 ? 6 : (units_per_wave4 >= 3 ? 5 : 4);
     const int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);
     for (int w = 4; w <= max_wpe; ++w)
         for (int b = 256; b <= kMaxBlock; b *= 2) {
@@ -614,7 +614,6 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const float4* fp = (const float4*)c->d_fprims;
     if (path && canon) hipLaunchKernelGGL((render_kernel<true, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (!path && canon) hipLaunchKernelGGL((render_kernel<false, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (path && wpe == 7) hipLaunchKernelGGL((render_kernel<true, false, 7>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (path && wpe == 6) hipLaunchKernelGGL((render_kernel<true, false, 6>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (path && wpe == 5) hipLaunchKernelGGL((render_kernel<true, false, 5>), dim3(grid), dim3(block), lds, c->stream, p, fp);
     else if (path) hipLaunchKernelGGL((render_kernel<true, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
