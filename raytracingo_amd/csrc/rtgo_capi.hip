@@ -566,7 +566,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
     const int fast_nodes = c->n_small > 0 ? 2 * c->n_small - 1 : 0;
     const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims) * sizeof(float4) +
-                             (size_t)kMaxLights * sizeof(LightRec);
+                             (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float);   // + the raygen constants
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
     size_t lds = 0;
     // Waves per SIMD the kernel variant is compiled for: 4 (<= 128 VGPRs), 5 (<= 96, level records in LDS), 6 (<= 80, some spills).

@@ -816,7 +816,10 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     // 15-20 VGPRs -- that is what lets the allocation fit 96 registers without spilling to scratch
     constexpr bool LVLDS = (WPE >= 5);
     constexpr int LVW = PATH ? 3 : 4;   // words per level record: the weight (path) / the term and the primitive (distributed)
-    float* s_lv = reinterpret_cast<float*>(s_lights + kMaxLights) + threadIdx.x;
+    // raygen constants (eye, U, V, W, image size, sample step): read from LDS where a sample starts, instead of sitting in
+    // registers through the ray loop
+    float* s_cam = reinterpret_cast<float*>(s_lights + kMaxLights);
+    float* s_lv = s_cam + 16 + threadIdx.x;
 
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid < kQueues) p.queue_next[kQueueStride * (unsigned int)tid] = 0u;
@@ -835,6 +838,12 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         for (int i = tid; i < 4 * p.n_prims; i += kBlock) s_prims[i] = p.fprims[i];
         for (int i = tid; i < 3 * p.n_prims; i += kBlock) s_mat_w[i] = p.prims[6 * (i / 3) + 3 + (i % 3)];
     }
+    if (threadIdx.x == 0) {
+        s_cam[0] = p.eye.x; s_cam[1] = p.eye.y; s_cam[2] = p.eye.z; s_cam[3] = (float)p.W;
+        s_cam[4] = p.U.x; s_cam[5] = p.U.y; s_cam[6] = p.U.z; s_cam[7] = (float)p.H;
+        s_cam[8] = p.V.x; s_cam[9] = p.V.y; s_cam[10] = p.V.z; s_cam[11] = 1.0f / (float)p.sqrt_spp;
+        s_cam[12] = p.Wv.x; s_cam[13] = p.Wv.y; s_cam[14] = p.Wv.z; s_cam[15] = 0.0f;
+    }
     {
         const float* src = reinterpret_cast<const float*>(p.lights);
         float* dst = reinterpret_cast<float*>(s_lights);
@@ -848,8 +857,6 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     float2* s_stack = s_stack_base + tid;
     const int lane = tid & 63;
     const unsigned int nn = (unsigned int)(p.sqrt_spp * p.sqrt_spp);
-    const float inc = 1.0f / (float)p.sqrt_spp;
-    const float dimX = (float)p.W, dimY = (float)p.H;
     // Work decomposition: ONE LANE = ONE PATH.  A wave takes "units" of 64/nn_eff neighbouring pixels of a row and runs
     // nn_eff = min(nn, 16) samples of each side by side, in ceil(nn / nn_eff) passes.  The samples of a pixel are independent
     // given the LCG state their jitter starts from (trace passes the seed by value, kernel.cu:46-79), which is the pixel's
@@ -963,10 +970,13 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         const unsigned int si = k / (unsigned int)p.sqrt_spp, sj = k - si * (unsigned int)p.sqrt_spp;
         const float r0 = rnd(seed);
         const float r1 = rnd(seed);
-        const float dx = 2.0f * ((fx + ((float)si + r0) * inc) / dimX) - 1.0f;
-        const float dy = 2.0f * ((fy + ((float)sj + r1) * inc) / dimY) - 1.0f;
-        v3 ro = p.eye;
-        v3 rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.Wv));
+        const float4 cam0 = reinterpret_cast<const float4*>(s_cam)[0], cam1 = reinterpret_cast<const float4*>(s_cam)[1],
+                     cam2 = reinterpret_cast<const float4*>(s_cam)[2], cam3 = reinterpret_cast<const float4*>(s_cam)[3];
+        const float inc = cam2.w;
+        const float dx = 2.0f * ((fx + ((float)si + r0) * inc) / cam0.w) - 1.0f;
+        const float dy = 2.0f * ((fy + ((float)sj + r1) * inc) / cam1.w) - 1.0f;
+        v3 ro = mk(cam0.x, cam0.y, cam0.z);
+        v3 rd = vnormalize(vadd(vadd(vscale(mk(cam1.x, cam1.y, cam1.z), dx), vscale(mk(cam2.x, cam2.y, cam2.z), dy)), mk(cam3.x, cam3.y, cam3.z)));
         float tmin = 0.05f, tmax = 1e16f;
         v3 result = mk(0.0f, 0.0f, 0.0f);   // payload of this sample's primary ray
         bool any_hit = false;
