@@ -29,6 +29,9 @@ typedef struct rtgo_host_scene {
    window, balls, checkered).  returns 0, or RTGO_E_INVALID for an unknown name. */
 int rtgo_host_scene_build(const char* scene_name, uint32_t width, uint32_t height, rtgo_host_scene* out);
 
+/* engine::host::materials::<name> (engine/materials.h:13-283) as kd[3], kr[3], Le[3], specularity; RTGO_E_INVALID for an unknown name */
+int rtgo_host_material(const char* name, float* out10);
+
 /* Headless engine::host::Renderer run: `frames` progressive frames of scene_name at width x height.
    mode: "path" or "distributed" (engine/main.cpp:83-103); sample = --sample; ambient = --useAmbient.
    host_image (uchar4, may be NULL) / host_accum (float4, may be NULL) receive the last frame; stats may be NULL.

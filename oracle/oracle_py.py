@@ -101,6 +101,8 @@ def lib():
         L.oracle_hemisphere.argtypes = [fp, fp, C.c_float, u32p, fp]
         L.oracle_scene_create.restype = C.c_int
         L.oracle_scene_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(Scene)]
+        L.oracle_material.restype = C.c_int
+        L.oracle_material.argtypes = [C.c_char_p, fp]
         L.oracle_lbvh_build.restype = C.c_int
         L.oracle_lbvh_build.argtypes = [C.c_void_p, C.c_int, C.POINTER(Node), u32p, C.POINTER(C.c_int32)]
         L.oracle_render.restype = C.c_int
@@ -124,6 +126,12 @@ def scene(name, width, height):
     if lib().oracle_scene_create(name.encode(), width, height, C.byref(sc)) != 0:
         raise ValueError("unknown scene %r" % name)
     return sc
+
+
+def material(name):
+    """engine/materials.h constant `name` as the oracle states it: kd[3], kr[3], Le[3], specularity (None: unknown name)"""
+    v = np.zeros(10, dtype=np.float32)
+    return v if lib().oracle_material(name.encode(), fptr(v)) == 0 else None
 
 
 def scene_tables(sc):

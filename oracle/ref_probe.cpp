@@ -5,14 +5,16 @@
 // oracle/_ref/libref_probe.so.  It contains no reference code: it only calls it, so that oracle/gen_golden.py can
 // record golden vectors (tests/golden/ref_*.json) that pin the restatement in oracle/rtgo_oracle.c bit for bit.
 //
-// These are the only parts of the hot path's arithmetic that compile here without OptiX: engine/*.cpp, params.h and
-// kernel.cu all include <optix.h> (absent from this image) and are therefore unbuildable -- see DESIGN.md.
+// Also compiled in: engine/materials.h + engine/basicmaterial.{h,cpp} (glm only): the 33 material constants of the scenes.
+// These are the only parts of the hot path's arithmetic that compile here without OptiX: the rest of engine/*.cpp, params.h
+// and kernel.cu all include <optix.h> (absent from this image) and are therefore unbuildable -- see DESIGN.md.
 // vector_types.h / vector_functions.h come from the CUDA headers this image ships inside the triton wheel.
 #include <sutil/Matrix.h>
 #include <sutil/vec_math.h>
 #include <sutil/Camera.h>
 #include <random.h>
 #include <glm/glm.hpp>
+#include <materials.h>   // engine/materials.h:13-283 (includes <basicmaterial.h>)
 
 #include <cstring>
 #include <cstdint>
@@ -96,6 +98,55 @@ void ref_glm_normal(const float* v1, const float* v2, float* out)
 {
     glm::vec3 n = glm::normalize(glm::cross(glm::vec3(v1[0], v1[1], v1[2]), glm::vec3(v2[0], v2[1], v2[2])));
     out[0] = n.x; out[1] = n.y; out[2] = n.z;
+}
+
+// engine/materials.h: the material constants by name -> kd[3], kr[3], Le[3], specularity (BasicMaterial getters, basicmaterial.h:36-50)
+int ref_material_count(void) { return 33; }
+int ref_material(int index, char* name_out, int name_cap, float* out10)
+{
+    namespace M = engine::host::materials;
+    static const struct { const char* name; const engine::host::BasicMaterial* m; } table[] = {
+        {"blackMirror", &M::blackMirror},
+        {"blue", &M::blue},
+        {"grey", &M::grey},
+        {"cream", &M::cream},
+        {"white", &M::white},
+        {"mirrorSpheresBlackMirror", &M::mirrorSpheresBlackMirror},
+        {"mirrorSpheresGroundMat", &M::mirrorSpheresGroundMat},
+        {"mirrorSpheresMetallicOrange", &M::mirrorSpheresMetallicOrange},
+        {"mirrorSpheresSilver", &M::mirrorSpheresSilver},
+        {"plateMetallicGold", &M::plateMetallicGold},
+        {"platePurple", &M::platePurple},
+        {"plateCyan", &M::plateCyan},
+        {"platePrettyGreen", &M::platePrettyGreen},
+        {"plateDarkRed", &M::plateDarkRed},
+        {"plateYellow", &M::plateYellow},
+        {"plateLight", &M::plateLight},
+        {"cornellMirror", &M::cornellMirror},
+        {"cornellWhite", &M::cornellWhite},
+        {"cornellBlue", &M::cornellBlue},
+        {"cornellRed", &M::cornellRed},
+        {"cornellLight", &M::cornellLight},
+        {"softMirrorsMirror0", &M::softMirrorsMirror0},
+        {"softMirrorsMirror1", &M::softMirrorsMirror1},
+        {"softMirrorsMirror2", &M::softMirrorsMirror2},
+        {"softMirrorsMirror3", &M::softMirrorsMirror3},
+        {"softMirrorsMirror4", &M::softMirrorsMirror4},
+        {"softMirrorsMirror5", &M::softMirrorsMirror5},
+        {"softMirrorsMirror6", &M::softMirrorsMirror6},
+        {"softMirrorsMirror7", &M::softMirrorsMirror7},
+        {"CheckeredLight", &M::CheckeredLight},
+        {"BallsLight", &M::BallsLight},
+        {"WindowLight", &M::WindowLight},
+        {"windowWhite", &M::windowWhite}
+    };
+    if (index < 0 || index >= (int)(sizeof table / sizeof table[0])) return -1;
+    std::strncpy(name_out, table[index].name, (size_t)name_cap - 1);
+    name_out[name_cap - 1] = 0;
+    const glm::vec3 kd = table[index].m->GetKd(), kr = table[index].m->GetKr(), le = table[index].m->GetLe();
+    const float v[10] = {kd.x, kd.y, kd.z, kr.x, kr.y, kr.z, le.x, le.y, le.z, table[index].m->GetSpecularity()};
+    std::memcpy(out10, v, sizeof v);
+    return 0;
 }
 
 } // extern "C"

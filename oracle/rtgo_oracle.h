@@ -125,6 +125,7 @@ void oracle_hemisphere(const float* normal, const float* direction, float coef, 
 /* --- scenes: scene.cpp:29-671 + renderer.cpp:321-336,386-453,655-677 flattening. returns 0 or -1 (unknown name).
    names are the CLI names of main.cpp:44-52. */
 int oracle_scene_create(const char* name, uint32_t width, uint32_t height, oracle_scene* out);
+int oracle_material(const char* name, float* out10);           /* engine/materials.h:13-283 by name: kd, kr, Le, specularity */
 
 /* --- canonical LBVH: nodes must hold 2n-1 entries; returns root index (0, or 0 for n==1 leaf) */
 int oracle_lbvh_build(const float (*aabb)[6], int n, oracle_node* nodes, uint32_t* morton_sorted, int32_t* prim_sorted);

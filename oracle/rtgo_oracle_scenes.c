@@ -46,6 +46,46 @@ MAT(m_windowWhite, 0.9f, 0.9f, 0.9f, 0.5f, 0.5f, 0.5f, 0.0f, 0.0f, 0.0f, 100.0f)
 /* softMirrorsMirror0..7 (materials.h:188-249): same kd/kr, specularity table */
 static const float SOFT_MIRROR_SPEC[8] = { 500000.0f, 100000.0f, 50000.0f, 10000.0f, 5000.0f, 1000.0f, 500.0f, 100.0f };
 
+/* materials.h constants no scene at HEAD uses, kept so that the whole table is held to the reference (tests/golden/ref_blocks.json) */
+MAT(m_blackMirror, 0.1f, 0.1f, 0.1f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f);                       /* :13-18 */
+MAT(m_blue, 0.0f, 0.549f, 0.988f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f);                          /* :21-26 */
+MAT(m_white, 0.8f, 0.8f, 0.8f, 0.3f, 0.3f, 0.3f, 0.0f, 0.0f, 0.0f, 1.0f);                             /* :44-49 */
+MAT(m_plateLight, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 15.f, 15.f, 15.f, 0.0f);                        /* :137-142 */
+MAT(m_cornellMirror, 0.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f);                     /* :147-152 */
+
+/* the table by the reference's names: kd[3], kr[3], Le[3], specularity.  returns 0, or -1 for an unknown name */
+int oracle_material(const char* name, float* out10)
+{
+    static const struct { const char* name; const omat* m; } table[] = {
+        { "blackMirror", &m_blackMirror }, { "blue", &m_blue }, { "grey", &m_grey }, { "cream", &m_cream }, { "white", &m_white },
+        { "mirrorSpheresBlackMirror", &m_msBlackMirror }, { "mirrorSpheresGroundMat", &m_msGround },
+        { "mirrorSpheresMetallicOrange", &m_msOrange }, { "mirrorSpheresSilver", &m_msSilver },
+        { "plateMetallicGold", &m_plateGold }, { "platePurple", &m_platePurple }, { "plateCyan", &m_plateCyan },
+        { "platePrettyGreen", &m_plateGreen }, { "plateDarkRed", &m_plateDarkRed }, { "plateYellow", &m_plateYellow },
+        { "plateLight", &m_plateLight }, { "cornellMirror", &m_cornellMirror }, { "cornellWhite", &m_cornellWhite },
+        { "cornellBlue", &m_cornellBlue }, { "cornellRed", &m_cornellRed }, { "cornellLight", &m_cornellLight },
+        { "CheckeredLight", &m_light12 }, { "BallsLight", &m_light12 }, { "WindowLight", &m_light12 }, { "windowWhite", &m_windowWhite },
+    };
+    omat m;
+    int found = 0;
+    for (size_t i = 0; i < sizeof table / sizeof table[0] && !found; ++i)
+        if (strcmp(name, table[i].name) == 0) {
+            m = *table[i].m;
+            found = 1;
+        }
+    if (!found && strncmp(name, "softMirrorsMirror", 17) == 0 && name[17] >= '0' && name[17] <= '7' && name[18] == 0) {
+        m = m_msBlackMirror;                       /* materials.h:188-249: kd 0.05, kr 1, Le 0 */
+        m.spec = SOFT_MIRROR_SPEC[name[17] - '0'];
+        found = 1;
+    }
+    if (!found) return -1;
+    memcpy(out10 + 0, m.kd, sizeof m.kd);
+    memcpy(out10 + 3, m.kr, sizeof m.kr);
+    memcpy(out10 + 6, m.le, sizeof m.le);
+    out10[9] = m.spec;
+    return 0;
+}
+
 typedef struct {
     int n;
     oracle_prim p[8];

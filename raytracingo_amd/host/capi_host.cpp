@@ -1,6 +1,7 @@
 // capi_host.cpp -- the C view of the host surface declared in include/rtgo_host.h.
 #include <rtgo_host.h>
 
+#include "materials.h"
 #include "renderer.h"
 
 #include <cstring>
@@ -30,6 +31,36 @@ bool scene_from_name(const std::string& s, SceneModel& out)
 extern "C" {
 
 const char* rtgo_host_last_error(void) { return g_error.c_str(); }
+
+int rtgo_host_material(const char* name, float* out10)
+{
+    namespace M = materials;
+    static const struct { const char* name; const BasicMaterial* m; } table[] = {
+        {"blackMirror", &M::blackMirror}, {"blue", &M::blue}, {"grey", &M::grey}, {"cream", &M::cream}, {"white", &M::white},
+        {"mirrorSpheresBlackMirror", &M::mirrorSpheresBlackMirror}, {"mirrorSpheresGroundMat", &M::mirrorSpheresGroundMat},
+        {"mirrorSpheresMetallicOrange", &M::mirrorSpheresMetallicOrange}, {"mirrorSpheresSilver", &M::mirrorSpheresSilver},
+        {"plateMetallicGold", &M::plateMetallicGold}, {"platePurple", &M::platePurple}, {"plateCyan", &M::plateCyan},
+        {"platePrettyGreen", &M::platePrettyGreen}, {"plateDarkRed", &M::plateDarkRed}, {"plateYellow", &M::plateYellow},
+        {"plateLight", &M::plateLight}, {"cornellMirror", &M::cornellMirror}, {"cornellWhite", &M::cornellWhite},
+        {"cornellBlue", &M::cornellBlue}, {"cornellRed", &M::cornellRed}, {"cornellLight", &M::cornellLight},
+        {"softMirrorsMirror0", &M::softMirrorsMirror0}, {"softMirrorsMirror1", &M::softMirrorsMirror1},
+        {"softMirrorsMirror2", &M::softMirrorsMirror2}, {"softMirrorsMirror3", &M::softMirrorsMirror3},
+        {"softMirrorsMirror4", &M::softMirrorsMirror4}, {"softMirrorsMirror5", &M::softMirrorsMirror5},
+        {"softMirrorsMirror6", &M::softMirrorsMirror6}, {"softMirrorsMirror7", &M::softMirrorsMirror7},
+        {"CheckeredLight", &M::CheckeredLight}, {"BallsLight", &M::BallsLight}, {"WindowLight", &M::WindowLight},
+        {"windowWhite", &M::windowWhite},
+    };
+    if (!name || !out10) return RTGO_E_INVALID;
+    for (const auto& e : table)
+        if (std::strcmp(name, e.name) == 0) {
+            const glm::vec3 kd = e.m->GetKd(), kr = e.m->GetKr(), le = e.m->GetLe();
+            const float v[10] = {kd.x, kd.y, kd.z, kr.x, kr.y, kr.z, le.x, le.y, le.z, e.m->GetSpecularity()};
+            std::memcpy(out10, v, sizeof v);
+            return RTGO_OK;
+        }
+    g_error = std::string("rtgo_host_material: unknown material ") + name;
+    return RTGO_E_INVALID;
+}
 
 int rtgo_host_scene_build(const char* scene_name, uint32_t width, uint32_t height, rtgo_host_scene* out)
 {

@@ -37,8 +37,19 @@ def load():
         L.rtgo_host_render.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.POINTER(capi.Stats)]
         L.rtgo_host_last_error.restype = C.c_char_p
+        L.rtgo_host_material.restype = C.c_int
+        L.rtgo_host_material.argtypes = [C.c_char_p, C.POINTER(C.c_float)]
         _lib = L
     return _lib
+
+
+def material(name):
+    """engine::host::materials::<name> of the product host: kd[3], kr[3], Le[3], specularity"""
+    v = np.zeros(10, dtype=np.float32)
+    rc = load().rtgo_host_material(name.encode(), v.ctypes.data_as(C.POINTER(C.c_float)))
+    if rc:
+        raise capi.RtgoError("rtgo_host_material(%s): %s" % (name, load().rtgo_host_last_error().decode()))
+    return v
 
 
 def build(name, width, height):

@@ -85,3 +85,17 @@ def test_cli_fails_loudly_without_a_gpu():
         pytest.skip("GPU present")
     r = subprocess.run([ENGINE, "--mode=path", "--scene=cornell", "--dim=32x32"], capture_output=True, text=True)
     assert r.returncode == 1 and "Caught exception" in r.stderr and "no CPU path" in r.stderr
+
+
+def test_host_materials_are_the_references(hscene):
+    """the product host's engine::host::materials table against the reference's own constants (tests/golden/ref_blocks.json,
+    recorded through the reference's BasicMaterial getters by oracle/gen_golden.py): bit for bit"""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ref_blocks.json")) as f:
+        mats = json.load(f)["materials"]
+    assert len(mats) == 33
+    for name, want in mats.items():
+        got = hscene.material(name)
+        assert got.view(np.uint32).tolist() == want, (name, got.tolist())
+    with pytest.raises(Exception):
+        hscene.material("teapot")

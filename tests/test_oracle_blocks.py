@@ -108,3 +108,26 @@ def test_scene_inverses_use_the_pinned_inverse(oracle, ref):
     x = np.float32(3.14159265358979323846) / np.float32(3.0)
     assert np.float32(math.cos(float(x))) == np.cos(x, dtype=np.float32)
     assert np.float32(math.sin(float(x))) == np.sin(x, dtype=np.float32)
+
+
+def test_materials_are_the_references(oracle, ref):
+    """the 33 constants of engine/materials.h:13-283, read through the reference's own BasicMaterial getters
+    (oracle/ref_probe.cpp over materials.h + basicmaterial.cpp), against the oracle's table: bit for bit, name for name"""
+    assert len(ref["materials"]) == 33
+    for name, want in ref["materials"].items():
+        got = oracle.material(name)
+        assert got is not None, name
+        assert b(got) == want, (name, got.tolist(), f(want).tolist())
+    assert oracle.material("teapot") is None
+
+
+def test_every_scene_material_is_a_pinned_constant(oracle, ref):
+    """each primitive of each scene carries one of the pinned constants (scene.cpp picks them by name; balls picks them
+    through the scene RNG, scene.cpp:592-604)"""
+    pinned = {tuple(v) for v in ref["materials"].values()}
+    for name in oracle.SCENES:
+        t = oracle.scene_tables(oracle.scene(name, 64, 64))
+        m = t["mat"]    # kd, kr, specularity, Le (rtgo_prim order)
+        for row in m:
+            key = tuple(b(np.concatenate([row[0:6], row[7:10], row[6:7]])))
+            assert key in pinned, (name, row.tolist())
