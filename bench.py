@@ -19,20 +19,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+LDS_PEAK_GBS = 150000.0  # ds_read_b64/b128 with every CU streaming at ~2.4 GHz, same guide, "LDS"
 
 
-def pmc_traffic(scene, W, H, mode, N):
-    """HBM bytes per launch from the newest committed PMC profile of this workload (profiles/*/summary.json, produced by
-    tools/profile_round.sh with separate --pmc passes for FETCH_SIZE and WRITE_SIZE); None when there is none."""
+def committed_profile(scene, W, H, mode, N):
+    """The newest committed PMC profile of this workload (profiles/*/summary.json, written by tools/profile_round.sh from separate
+    rocprofv3 --pmc passes): HBM bytes per launch, and what binds the kernel -- vector issue slots filled, lanes live in them,
+    vector / scalar instructions per traversed ray.  None when there is none."""
     import glob
     best = None
     key = "%s %dx%d --mode=%s --sample=%d" % (scene, W, H, mode, N)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json")), key=os.path.getmtime):
         try:
             j = json.load(open(f))
             if key in j["bench"]["config"]["workload"] and "hbm_traffic_bytes_per_launch" in j:
-                best = (j["hbm_traffic_bytes_per_launch"], os.path.relpath(f, ROOT),
-                        {k: round(j[k], 4) for k in ("valu_issue_busy", "valu_lane_utilisation") if k in j})
+                best = (j, os.path.relpath(f, ROOT))
         except Exception:
             pass
     return best
@@ -249,19 +250,20 @@ def main():
                     tot[k] += st_[k]
         return tot
 
-    # ---- V, T, h of the workload (instrumented kernel, untimed, into scratch buffers so the accumulation is untouched)
+    # ---- V, T, h of the workload's TRAVERSED rays (instrumented kernel with the same background culling as the timed one,
+    #      collect_stats = 2; untimed, into scratch buffers so the accumulation is untouched)
     for i in range(S):
         bind(i, scratch_a, scratch_i)
         ctxs[i].reset_stats()
-        ctxs[i].launch(frame(args.warmup, i, stats=True))
+        ctxs[i].launch(frame(args.warmup, i, stats=2))
     for c in ctxs:
         c.sync()
     st = stats_sum()
     rdev = torch.device("cpu") if rehearse else dev   # gloo reduces host tensors
-    cnt = torch.tensor([st["rays_total"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=rdev)
+    cnt = torch.tensor([st["rays_total"] - st["rays_culled"], st["node_visits"], st["prim_tests"], st["hits"], st["rays_occlusion"]], dtype=torch.float64, device=rdev)
     if multi:
         dist.all_reduce(cnt)
-    rays_s, nodes_s, tests_s, hits_s, occl_s = [float(x) for x in cnt.tolist()]
+    rays_s, nodes_s, tests_s, hits_s, occl_s = [float(x) for x in cnt.tolist()]   # rays_s: traversed rays of one frame
     Vbar, Tbar, hbar = nodes_s / rays_s, tests_s / rays_s, hits_s / rays_s
     A_ray = 32 + 32 + 32 * Vbar + 64 * Tbar + 40 * hbar
     A_px = 36                                             # frame > 0: float4 read + float4 write + uchar4 write
@@ -293,15 +295,39 @@ def main():
     kernel_ms = float(km.item())          # slowest rank's average megakernel duration (HIP events on the launch stream)
 
     if rank == 0:
-        traffic = pmc_traffic(args.scene, W, H, args.mode, N)
+        prof = committed_profile(args.scene, W, H, args.mode, N) if world == 1 else None
         ms_per_step = dt / args.steps * 1e3
-        mrays = rays_total / dt / 1e6
-        rays_per_launch = rays_total / args.steps
-        alg_bytes = rays_per_launch * A_ray + W * H * A_px       # whole frame (all ranks)
-        achieved = alg_bytes / world / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0   # per GPU, GB/s
+        rays_per_launch = rays_total / args.steps                      # optixTrace equivalents per frame, all ranks
+        trav_per_launch = (rays_total - rays_culled) / args.steps      # ... of which a traversal answered
+        kernel_s = kernel_ms * 1e-3
+        # HBM roofline: with the scene resident in LDS, the bytes the algorithm moves through HBM are the framebuffer's
+        # (A_px = 36 B per pixel-frame on frames > 0: float4 accumulation read + write, uchar4 image write)
+        hbm_alg = W * H * A_px / world
+        achieved = hbm_alg / kernel_s / 1e9 if kernel_s > 0 else 0.0
+        # SURVEY 8d's per-ray byte model, on the traversed rays: node and primitive records and materials -- bytes this design
+        # serves from LDS and the scalar cache, never from HBM, so they are priced against the LDS peak, not against HBM's
+        ray_bytes = trav_per_launch * A_ray / world
+        flop_per_ray = 40 * Vbar + 100 * Tbar + 250 * hbar
+        binding = None
+        if prof:
+            j = prof[0]
+            c = j.get("pmc_per_launch", {})
+            prof_trav = j["bench"]["config"].get("rays_per_frame", 0) - j["bench"]["config"].get("rays_culled_per_frame", 0)
+            binding = {"bound": "valu_issue",
+                       "valu_issue_busy": round(j.get("valu_issue_busy", 0.0), 4),
+                       "valu_lane_utilisation": round(j.get("valu_lane_utilisation", 0.0), 4),
+                       # share of the chip's vector lane-slots that do work: issue slots filled x lanes live in them
+                       "frac_binding": round(j.get("valu_issue_busy", 0.0) * j.get("valu_lane_utilisation", 0.0), 4),
+                       "valu_insts_per_traversed_ray": round(c.get("SQ_INSTS_VALU", 0.0) / prof_trav * 64.0, 1) if prof_trav else None,
+                       "salu_insts_per_traversed_ray": round(c.get("SQ_INSTS_SALU", 0.0) / prof_trav * 64.0, 1) if prof_trav else None,
+                       "insts_unit": "wave instructions per 64 traversed rays (one ray per lane)",
+                       "profile_kernel_ms": round(j.get("kernel_trace", {}).get("avg_ms", 0.0), 4),
+                       "source": prof[1]}
         out = {
             "metric": "Mray/s + ms/frame, %s %dx%d %s spp=%d" % (args.scene, W, H, args.mode, N * N),
-            "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # rays a traversal answered per second; the primary rays of pixels outside the scene's screen rectangle (the reference
+            # traces them, they miss) are answered without a walk and are NOT counted here: config.mrays_incl_culled_primary has them
+            "value": round((rays_total - rays_culled) / dt / 1e6, 2), "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic (procedural scene of the reference, fixed RNG seeds)",
             "config": {"workload": "%s %dx%d --mode=%s --sample=%d (%d spp), progressive frames %d..%d" %
@@ -310,31 +336,33 @@ def main():
                        "launches_per_frame_per_gpu": S,
                        "gather": "RCCL gather of uchar4 bands to rank 0 every frame, overlapped with the next frame's kernel" if (multi and not args.no_gather) else "none",
                        "rays_per_frame": int(round(rays_per_launch)),
-                       # primary rays of pixels outside the screen rectangle of the scene's bounds: counted (the reference traces
-                       # them, they miss) but answered by that rectangle instead of a traversal; the rate without them is given too
                        "rays_culled_per_frame": int(round(rays_culled / args.steps)),
-                       "mrays_traversed_only": round((rays_total - rays_culled) / dt / 1e6, 2)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": (round(traffic[0]) if traffic and world == 1 else None),
+                       "rays_traversed_per_frame": int(round(trav_per_launch)),
+                       "mrays_incl_culled_primary": round(rays_total / dt / 1e6, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": (round(prof[0]["hbm_traffic_bytes_per_launch"]) if prof else None),
                          "traffic_unit": "HBM bytes per launch, PMC (2*FETCH_SIZE+WRITE_SIZE)*1024",
-                         "traffic_source": (traffic[1] if traffic and world == 1 else None),
+                         "traffic_source": (prof[1] if prof else None),
+                         "algorithmic_bytes_per_launch": int(hbm_alg),
+                         "algorithmic_basis": "SURVEY 8d A_px = %d B per pixel-frame x %d x %d pixels: the scene (<= 512 primitives) is resident in LDS, "
+                                              "so the framebuffer is all the algorithm moves through HBM" % (A_px, W, H),
                          "kernel": "rtgo::render_kernel<%s,false>" % ("true" if path else "false"),
                          "kernel_ms": round(kernel_ms, 4),
                          "kernel_ms_basis": ("HIP events around each launch, averaged (slowest rank)" if S == 1 else
                                              "wall time per frame of the slowest rank: its two launches per frame overlap, and so do their event durations"),
-                         "A_ray_bytes": round(A_ray, 1), "A_px_bytes": A_px,
-                         "V": round(Vbar, 3), "T": round(Tbar, 3), "h": round(hbar, 4),
-                         "achieved_min": round((rays_per_launch * 168 + W * H * A_px) / world / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else 0.0,
-                         "mrays_roofline": round(HBM_PEAK_GBS * 1e3 / A_ray, 1),
-                         # what actually binds the kernel (PMC of the committed profile): vector issue slots filled, lanes live in them
-                         "secondary": ({"bound": "valu issue", **traffic[2]} if traffic and world == 1 and traffic[2] else None),
-                         # SURVEY 8d's second bound, on the same algorithmic counts: ~40 flop per node visit, ~100 per primitive test,
-                         # ~250 per shaded hit, against the 157.3 TFLOP/s f32 vector peak (MI355X_MICROARCH.md, peak table)
-                         "fp32_algorithmic": {"tflops": round(rays_per_launch * (40 * Vbar + 100 * Tbar + 250 * hbar) / world / (kernel_ms * 1e-3) / 1e12, 2) if kernel_ms > 0 else 0.0,
-                                              "peak_tflops": 157.3,
-                                              "flop_per_ray": round(40 * Vbar + 100 * Tbar + 250 * hbar, 1)},
-                         "note": "algorithmic bytes (SURVEY 8d) per launch / HIP-event kernel time; the scene is LDS-resident so physical HBM traffic is only the framebuffer"},
+                         # what binds the kernel: vector issue (PMC of the committed profile of this workload)
+                         "binding": binding,
+                         "on_chip_ray_model": {"A_ray_bytes": round(A_ray, 1), "V": round(Vbar, 3), "T": round(Tbar, 3), "h": round(hbar, 4),
+                                               "counted_over": "traversed rays (instrumented canonical-LBVH launch with the timed kernel's background culling)",
+                                               "bytes_per_launch": int(ray_bytes),
+                                               "rate_GBps": round(ray_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else 0.0,
+                                               "served_from": "LDS and the scalar cache (not HBM)",
+                                               "lds_peak_GBps": LDS_PEAK_GBS,
+                                               "share_of_lds_peak": round(ray_bytes / kernel_s / 1e9 / LDS_PEAK_GBS, 4) if kernel_s > 0 else 0.0,
+                                               "fp32_model_tflops": round(trav_per_launch * flop_per_ray / world / kernel_s / 1e12, 2) if kernel_s > 0 else 0.0,
+                                               "fp32_peak_tflops": 157.3, "flop_per_ray": round(flop_per_ray, 1)},
+                         "note": "frac is small by design: the kernel is bound by vector issue (binding), not by HBM"},
         }
         if args.single_rank_collectives:
             out["single_rank_collectives"] = "N>1 machinery with a world of one rank (developer check): NOT the N=1 measurement"

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTGO_ABI_VERSION 2
+#define RTGO_ABI_VERSION 3
 #define RTGO_MAX_PRIMS 512  /* scene staged whole in LDS (largest reference scene: checkered, 390) */
 #define RTGO_MAX_LIGHTS 10  /* Params::MAX_LIGHTS, engine/params.h:115 */
 
@@ -81,7 +81,9 @@ typedef struct rtgo_frame {
     uint32_t x0, y0, w, h;     /* window in global pixel coordinates; w = h = 0 means the full image */
     uint32_t band_h;           /* row-band height of the interleave inside the window (0 = 4) */
     uint32_t n_ranks, rank;    /* this context renders window rows r with (r / band_h) % n_ranks == rank; 0/1 = all */
-    uint32_t collect_stats;    /* 1: also count LBVH node visits / primitive tests / hits (slower instrumented kernel) */
+    uint32_t collect_stats;    /* 1: also count LBVH node visits / primitive tests / hits over every ray (slower instrumented kernel
+                                  on the canonical LBVH, every pixel traced); 2: the same counters over the TRAVERSED rays only
+                                  (pixels outside the scene's screen rectangle are answered without a walk, as in timed launches) */
     uint32_t reserve_cus;      /* leave this many CUs' worth of workgroup slots to other streams (the multi-GPU driver's RCCL
                                   gather overlaps the next frame's kernel; persistent workgroups would otherwise hold every CU) */
 } rtgo_frame;
@@ -100,6 +102,9 @@ typedef struct rtgo_stats {
     uint64_t dbg_fast_tests;  /* diagnostic builds only: leaf tests of the fast walk incl. the up-front list, else 0 */
     uint64_t rays_culled;     /* primary rays among rays_total that were answered (as misses) by the screen rectangle of the
                                  scene's bounds instead of a traversal; always 0 for collect_stats launches */
+    uint32_t launches_canonical; /* launches since rtgo_reset_stats that walked the canonical LBVH: collect_stats launches, and
+                                    launches whose scene or eye reaches beyond 500 units (several times slower) */
+    uint32_t reserved;
 } rtgo_stats;
 
 typedef struct rtgo_ctx rtgo_ctx;
@@ -163,6 +168,14 @@ int rtgo_reset_stats(rtgo_ctx* ctx);
    {float bmin[3]; int32 left; float bmax[3]; int32 right} ... see DESIGN.md; inverses = n x 12 floats (rows 0..2). */
 int rtgo_read_bvh(rtgo_ctx* ctx, void* host_nodes, size_t node_bytes, void* host_inverses, size_t inv_bytes,
                   void* host_aabbs, size_t aabb_bytes);
+
+/* Multi-GPU presentation step (no reference counterpart: the reference is single-GPU).  d_gathered holds
+   n_ranks compact band buffers back to back, rows_pad rows of w elements each (rank g's k-th owned row is row g*rows_pad + k:
+   what the ranks' rtgo_bind_output buffers look like after a gather to one root); d_full receives window rows 0..h-1.
+   elem_bytes = 4 (uchar4 image) or 16 (float4 accumulation).  Asynchronous on hip_stream (hipStream_t as void*; NULL = the
+   context's stream); both pointers are device memory of ctx's device. */
+int rtgo_assemble_bands(rtgo_ctx* ctx, void* hip_stream, const void* d_gathered, void* d_full, uint32_t w, uint32_t h,
+                        uint32_t band_h, uint32_t n_ranks, uint32_t rows_pad, uint32_t elem_bytes);
 
 /* number of window rows a rank owns under the band interleave (pure host arithmetic) */
 uint32_t rtgo_local_rows(uint32_t h, uint32_t band_h, uint32_t n_ranks, uint32_t rank);

@@ -41,6 +41,15 @@ int rtgo_host_render(const char* scene_name, const char* mode, uint32_t width, u
 
 /* A scripted interactive session with engine::host::Renderer: what the GLFW callbacks + frame loop of the reference do
    (renderer.cpp:36-145, 679-747, 841-862), without a window.  All return 0 or an RTGO_E_* code. */
+/* Headless engine::host::MultiGpuRenderer run (raytracingo_amd/host/multigpu.h): the frame tiled in 4-row bands over
+   n_devices GPUs x launches_per_device shares, accumulation bands resident per share, the 8-bit bands gathered to devices[0]
+   over RCCL (grouped ncclSend/ncclRecv) and assembled there every present_every-th frame and after the last one.
+   rccl_for_local_shares != 0 moves the root GPU's own bands through RCCL as well (one-GPU boxes can then exercise that path).
+   host_image / host_accum / stats / ms_per_frame may be NULL.  The assembled frame is bitwise what rtgo_host_render gives. */
+int rtgo_host_render_multi(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient, int frames,
+                           const int* devices, int n_devices, int launches_per_device, int present_every, int rccl_for_local_shares,
+                           void* host_image, void* host_accum, rtgo_stats* stats, double* ms_per_frame);
+
 typedef struct rtgo_host_session rtgo_host_session;
 int rtgo_host_session_open(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient,
                            int device, rtgo_host_session** out);

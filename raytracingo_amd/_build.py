@@ -1,7 +1,7 @@
 """Build the native parts of raytracingo_amd in-tree (the .so files travel to the GPU box with the snapshot).
 
   librtgo_hip.so   csrc/rtgo_capi.hip + rtgo_device.h   hipcc --offload-arch=gfx950   (the product: C ABI + kernels)
-  librtgo_host.so  host/*.cpp                            g++                           (Scene/Shape/Renderer mirror)
+  librtgo_host.so  host/*.cpp                            g++ (+ libamdhip64, librccl)  (Scene/Shape/Renderer mirror, multi-GPU driver)
   rtgo_engine      host/main.cpp                         g++                           (headless CLI of engine/main.cpp)
 """
 import os
@@ -20,6 +20,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
              "-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall"]
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+# the multi-GPU driver (host/multigpu.cpp) makes HIP runtime calls (streams, events, buffers) and RCCL calls from plain C++
+HOST_ROCM_FLAGS = ["-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include")]
+HOST_ROCM_LIBS = ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64", "-lrccl", "-Wl,-rpath," + os.path.join(ROCM, "lib")]
 
 
 def _stale(target, sources):
@@ -84,15 +88,16 @@ def build_host(force=False, verbose=False):
     if srcs and (force or _stale(out, srcs + hdrs)):
         with _build_lock():
             if force or _stale(out, srcs + hdrs):
-                _run_to(out, ["g++"] + HOST_FLAGS + ["-shared", "-I" + os.path.join(ROOT, "include"), "-I" + d],
-                        srcs + ["-L" + PKG, "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"], verbose)
+                # (only gpu_transport.cpp includes HIP / RCCL headers; the define is harmless for the others)
+                _run_to(out, ["g++"] + HOST_FLAGS + HOST_ROCM_FLAGS + ["-shared", "-I" + os.path.join(ROOT, "include"), "-I" + d],
+                        srcs + ["-L" + PKG, "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"] + HOST_ROCM_LIBS, verbose)
     exe = os.path.join(PKG, "rtgo_engine")
     main = os.path.join(d, "main.cpp")
     if os.path.exists(main) and (force or _stale(exe, [main, out] + hdrs)):
         with _build_lock():
             if force or _stale(exe, [main, out] + hdrs):
                 _run_to(exe, ["g++"] + HOST_FLAGS + ["-I" + os.path.join(ROOT, "include"), "-I" + d],
-                        [main, "-L" + PKG, "-lrtgo_host", "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"], verbose)
+                        [main, "-L" + PKG, "-lrtgo_host", "-lrtgo_hip", "-Wl,-rpath,$ORIGIN"] + HOST_ROCM_LIBS, verbose)
     return out
 
 

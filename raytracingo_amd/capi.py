@@ -21,7 +21,7 @@ SYMBOLS = [
     "rtgo_create", "rtgo_destroy", "rtgo_last_error", "rtgo_set_stream", "rtgo_set_scene", "rtgo_set_camera",
     "rtgo_set_background", "rtgo_set_lights", "rtgo_resize", "rtgo_bind_output", "rtgo_launch", "rtgo_sync",
     "rtgo_read_image", "rtgo_read_accum", "rtgo_write_accum", "rtgo_get_stats", "rtgo_reset_stats", "rtgo_read_bvh",
-    "rtgo_local_rows", "rtgo_abi_version",
+    "rtgo_local_rows", "rtgo_abi_version", "rtgo_assemble_bands",
 ]
 
 
@@ -56,7 +56,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_total", C.c_uint64), ("rays_occlusion", C.c_uint64), ("node_visits", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("last_launch_ms", C.c_float),
                 ("total_launch_ms", C.c_float), ("launches", C.c_uint32), ("lbvh_depth", C.c_uint32),
-                ("dbg_fast_boxes", C.c_uint64), ("dbg_fast_tests", C.c_uint64), ("rays_culled", C.c_uint64)]
+                ("dbg_fast_boxes", C.c_uint64), ("dbg_fast_tests", C.c_uint64), ("rays_culled", C.c_uint64),
+                ("launches_canonical", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -98,6 +99,7 @@ def load():
     L.rtgo_read_bvh.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_size_t]
     L.rtgo_local_rows.restype = C.c_uint32
     L.rtgo_local_rows.argtypes = [C.c_uint32] * 4
+    L.rtgo_assemble_bands.argtypes = [vp, vp, vp, vp] + [C.c_uint32] * 6
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("rtgo_last_error", "rtgo_local_rows", "rtgo_abi_version"):

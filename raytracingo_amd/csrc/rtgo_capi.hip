@@ -57,6 +57,7 @@ struct rtgo_ctx {
     unsigned int* d_queue = nullptr;          // two sets of work-queue heads: a launch counts on one and zeroes the other for the next
     int queue_set = 0;
     unsigned long long rays_culled = 0;       // since rtgo_reset_stats (host arithmetic: the cold pixels of each launch x N*N)
+    uint32_t launches_canonical = 0;          // since rtgo_reset_stats
     unsigned long long* d_counters = nullptr;  // 8 x u64
 #ifdef RTGO_CMPWALK
     float* d_cmp = nullptr;                    // diagnostic build: disagreements between the two walks
@@ -71,6 +72,25 @@ struct rtgo_ctx {
 };
 
 static std::string g_create_error;
+
+// every instantiation of the megakernel, in one place: rtgo_create raises the dynamic-LDS limit of each, rtgo_launch picks one
+using RenderKernel = void (*)(const LaunchParams, const float4*);
+struct RenderKernelEntry {
+    bool path, canon;
+    int wpe;
+    RenderKernel fn;
+};
+static const RenderKernelEntry kRenderKernels[] = {
+    {true, false, 4, render_kernel<true, false, 4>},   {true, false, 5, render_kernel<true, false, 5>},   {true, false, 6, render_kernel<true, false, 6>},
+    {false, false, 4, render_kernel<false, false, 4>}, {false, false, 5, render_kernel<false, false, 5>}, {false, false, 6, render_kernel<false, false, 6>},
+    {true, true, 4, render_kernel<true, true, 4>},     {false, true, 4, render_kernel<false, true, 4>},
+};
+static RenderKernel find_kernel(bool path, bool canon, int wpe)
+{
+    for (const RenderKernelEntry& e : kRenderKernels)
+        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe)) return e.fn;
+    return nullptr;
+}
 
 static int fail(rtgo_ctx* c, int code, const std::string& msg)
 {
@@ -240,11 +260,8 @@ int rtgo_create(int device, rtgo_ctx** out)
     if (err == hipSuccess) err = hipMalloc(&c->d_meta, 16 * sizeof(int));
     // the megakernel may use most of the 160 KiB LDS of a CU
     const int max_lds = 160 * 1024;
-    const void* kernels[6] = {(const void*)render_kernel<true, false, 4>,  (const void*)render_kernel<true, false, 5>,
-                              (const void*)render_kernel<false, false, 4>, (const void*)render_kernel<false, false, 5>,
-                              (const void*)render_kernel<true, true, 4>,   (const void*)render_kernel<false, true, 4>};
-    for (const void* k : kernels)
-        if (err == hipSuccess) err = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    for (const RenderKernelEntry& e : kRenderKernels)
+        if (err == hipSuccess) err = hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     if (err == hipSuccess) err = hipDeviceSynchronize();  // the null-stream memsets above must land before any launch
     if (err != hipSuccess) {
         std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
@@ -484,7 +501,9 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         p.bg_pixel = v3{sx * inv, sy * inv, sz * inv};
     }
     uint32_t wx0 = 0, wx1 = p.w, wy0 = 0, wy1 = p.h;
-    if (!stats && !std::getenv("RTGO_NO_CULL")) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);   // the instrumented kernel traces every pixel
+    // collect_stats 1: the instrumented kernel traces every pixel (V, T, h over ALL rays); 2: it culls like the timed
+    // kernel, so that the counters describe the traversed rays only
+    if (f->collect_stats != 1 && !std::getenv("RTGO_NO_CULL")) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);
     // The fast walk's tight boxes carry 1e-3 of padding against the rounding of the intersection programs, which grows with
     // the coordinates involved (~1e-7 of them for a rectangle's hit point).  Beyond 500 units -- the reference's scenes stay
     // within 20, its camera at 14 -- the launch takes the canonical walk instead: slower, and equal to it by definition.
@@ -559,6 +578,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.max_depth = f->max_trace_depth;
     p.frame = f->frame_count;
     p.ambient = f->use_ambient ? 1 : 0;
+    p.count_stats = stats ? 1 : 0;
     if (p.n_tiles == 0) return RTGO_OK;  // this rank owns no rows
 
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
@@ -576,7 +596,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // of fewer waves wins (a 1/16 share: 0.127 / 0.137 / 0.162 ms at 4 / 5 / 6).
     const uint64_t units_per_wave4 = units_hot * (passes_of(nn)) / ((uint64_t)c->num_cus * 16u);
     const int max_wpe_work = units_per_wave4 >= 12 ? 6 : (units_per_wave4 >= 3 ? 5 : 4);
-    const int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);
+    int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);   // (experiment knob, clamped to what exists)
+    max_wpe = max_wpe < 4 ? 4 : (max_wpe > 6 ? 6 : max_wpe);
     for (int w = 4; w <= max_wpe; ++w)
         for (int b = 256; b <= kMaxBlock; b *= 2) {
             const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
@@ -598,8 +619,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (grid > need) grid = need;
 
     if (std::getenv("RTGO_DEBUG"))
-        std::fprintf(stderr, "rtgo_launch: grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d\n",
-                     grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth);
+        std::fprintf(stderr, "rtgo_launch: %s walk%s, grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d\n",
+                     canon ? "canonical" : "fast", (canon && !stats) ? " (scene or eye beyond 500 units)" : "", grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth);
 #ifdef RTGO_TIMELINE
     c->timeline_waves = grid * (unsigned int)(block / 64);
     if (c->timeline_waves > 16384) return fail(c, RTGO_E_UNSUPPORTED, "timeline buffer too small");
@@ -612,14 +633,9 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const float4* fp = (const float4*)c->d_fprims;
-    if (path && canon) hipLaunchKernelGGL((render_kernel<true, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (!path && canon) hipLaunchKernelGGL((render_kernel<false, true, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (path && wpe == 6) hipLaunchKernelGGL((render_kernel<true, false, 6>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (path && wpe == 5) hipLaunchKernelGGL((render_kernel<true, false, 5>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (path) hipLaunchKernelGGL((render_kernel<true, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (wpe == 6) hipLaunchKernelGGL((render_kernel<false, false, 6>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else if (wpe == 5) hipLaunchKernelGGL((render_kernel<false, false, 5>), dim3(grid), dim3(block), lds, c->stream, p, fp);
-    else hipLaunchKernelGGL((render_kernel<false, false, 4>), dim3(grid), dim3(block), lds, c->stream, p, fp);
+    const RenderKernel kernel = find_kernel(path, canon, wpe);
+    if (!kernel) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: no kernel variant for this configuration");
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->queue_set = 1 - c->queue_set;
@@ -627,6 +643,34 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;
     c->ev_pending++;
     c->launches++;
+    if (canon) c->launches_canonical++;
+    return RTGO_OK;
+}
+
+int rtgo_assemble_bands(rtgo_ctx* c, void* hip_stream, const void* d_gathered, void* d_full, uint32_t w, uint32_t h, uint32_t band_h,
+                        uint32_t n_ranks, uint32_t rows_pad, uint32_t elem_bytes)
+{
+    if (!c || !d_gathered || !d_full) return fail(c, RTGO_E_INVALID, "rtgo_assemble_bands: NULL argument");
+    if (w == 0 || h == 0 || n_ranks == 0 || (elem_bytes != 4 && elem_bytes != 16))
+        return fail(c, RTGO_E_INVALID, "rtgo_assemble_bands: empty window, no ranks, or element size not 4 / 16");
+    if (band_h == 0) band_h = 4;
+    for (uint32_t g = 0; g < n_ranks; ++g)
+        if (rtgo_local_rows(h, band_h, n_ranks, g) > rows_pad) return fail(c, RTGO_E_INVALID, "rtgo_assemble_bands: rows_pad smaller than a rank's share");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const uint64_t row_bytes = (uint64_t)w * elem_bytes;
+    const bool wide = (row_bytes % 16 == 0) && (((uintptr_t)d_gathered | (uintptr_t)d_full) % 16 == 0);
+    const uint64_t units = (wide ? row_bytes / 16 : row_bytes / 4) * h;
+    uint64_t blocks = (units + 255) / 256;
+    const uint64_t cap = (uint64_t)c->num_cus * 16;
+    if (blocks > cap) blocks = cap;
+    if (wide)
+        hipLaunchKernelGGL(assemble_bands_kernel<uint4>, dim3((unsigned int)blocks), dim3(256), 0, st, (const uint4*)d_gathered, (uint4*)d_full,
+                           (unsigned int)(row_bytes / 16), h, band_h, n_ranks, rows_pad);
+    else
+        hipLaunchKernelGGL(assemble_bands_kernel<unsigned int>, dim3((unsigned int)blocks), dim3(256), 0, st, (const unsigned int*)d_gathered,
+                           (unsigned int*)d_full, (unsigned int)(row_bytes / 4), h, band_h, n_ranks, rows_pad);
+    RTGO_HIP(c, hipGetLastError());
     return RTGO_OK;
 }
 
@@ -685,6 +729,8 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     out->dbg_fast_boxes = h[5];
     out->dbg_fast_tests = h[6];
     out->rays_culled = c->rays_culled;
+    out->launches_canonical = c->launches_canonical;
+    out->reserved = 0;
     return RTGO_OK;
 }
 
@@ -699,6 +745,7 @@ int rtgo_reset_stats(rtgo_ctx* c)
     c->total_ms = 0.0f;
     c->last_ms = 0.0f;
     c->launches = 0;
+    c->launches_canonical = 0;
     c->rays_culled = 0;
     return RTGO_OK;
 }

@@ -58,6 +58,7 @@ struct LaunchParams {
     int sqrt_spp, max_depth;
     unsigned int frame;
     int ambient;
+    int count_stats;                // canonical walk only: flush the V/T/h counters (0 when the walk is a fallback, not a request)
     unsigned int x0, y0, w, h;      // window
     unsigned int band_h, n_ranks, rank, local_rows;
     unsigned int n_tiles;            // work-queue entries of this launch = n_hot strips, then n_cold chunks
@@ -792,8 +793,9 @@ __device__ __forceinline__ void cold_segment(const LaunchParams& p, unsigned int
 // PATH = Params::enablePathTracing.  STATS = false: the fast walk (timed kernel).  STATS = true: the canonical LBVH walk with
 // the V/T/h counters that define the roofline's algorithmic bytes; both produce the same pixels bit for bit.
 // =====================================================================================================================
-// WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs, no spills) for scenes whose LDS image limits a CU to
-// 16 waves anyway, 5 (<= 96 VGPRs, a few spilled dwords) for small scenes, where the fifth wave buys more than the spills cost.
+// WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs) for scenes whose LDS image limits a CU to 16 waves
+// anyway, 5 (<= 96 VGPRs) and 6 (<= 80 VGPRs) for small scenes, where the extra waves buy more than the tighter budget costs
+// (rtgo_capi.hip picks per launch; kRenderKernels there lists every instantiation).
 template <bool PATH, bool STATS, int WPE>
 __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
@@ -1264,7 +1266,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     if (lane == 0) {
         atomicAdd(&p.counters[0], (unsigned long long)c_rays);
         if (!PATH) atomicAdd(&p.counters[1], (unsigned long long)c_occl);
-        if (STATS) {
+        if (STATS && p.count_stats) {
             atomicAdd(&p.counters[2], (unsigned long long)c_nodes);
             atomicAdd(&p.counters[3], (unsigned long long)c_tests);
             atomicAdd(&p.counters[4], (unsigned long long)c_hits);
@@ -1758,6 +1760,24 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     if (i == 0) {
         out_meta[1] = s_depth;
         out_meta[2] = n_small;
+    }
+}
+
+// =====================================================================================================================
+// Presentation step of the multi-GPU driver: the root holds n_ranks compact band buffers back to back (rows_pad rows each) and
+// scatters their rows to the rows of the full window they belong to under the band interleave.  T = uint4 (16-byte units) or
+// unsigned int (4-byte units); row_units = units per row.  Pure copy: HBM-bound, one unit per thread, coalesced both ways.
+// =====================================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_bands_kernel(const T* __restrict__ gathered, T* __restrict__ full, unsigned int row_units,
+                                                            unsigned int h, unsigned int band_h, unsigned int n_ranks, unsigned int rows_pad)
+{
+    const unsigned long long total = (unsigned long long)row_units * h;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned int r = (unsigned int)(i / row_units), x = (unsigned int)(i - (unsigned long long)r * row_units);
+        const unsigned int band = r / band_h, g = band % n_ranks;
+        const unsigned int k = (band / n_ranks) * band_h + (r - band * band_h);   // rank g's local row
+        full[i] = gathered[((unsigned long long)g * rows_pad + k) * row_units + x];
     }
 }
 

@@ -2,6 +2,7 @@
 #include <rtgo_host.h>
 
 #include "materials.h"
+#include "multigpu.h"
 #include "renderer.h"
 
 #include <cstring>
@@ -135,6 +136,47 @@ int rtgo_host_render(const char* scene_name, const char* mode, uint32_t width, u
             std::memcpy(host_accum, acc.data(), acc.size() * sizeof(float));
         }
         if (stats) *stats = renderer.Stats();
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return RTGO_E_STATE;
+    }
+    return RTGO_OK;
+}
+
+int rtgo_host_render_multi(const char* scene_name, const char* mode, uint32_t width, uint32_t height, int sample, int ambient, int frames,
+                           const int* devices, int n_devices, int launches_per_device, int present_every, int rccl_for_local_shares,
+                           void* host_image, void* host_accum, rtgo_stats* stats, double* ms_per_frame)
+{
+    SceneModel model;
+    if (!scene_name || !mode || !scene_from_name(scene_name, model) || width == 0 || height == 0 || sample < 1 || frames < 1 || !devices || n_devices < 1) {
+        g_error = "rtgo_host_render_multi: bad argument";
+        return RTGO_E_INVALID;
+    }
+    const std::string m(mode);
+    if (m != "path" && m != "distributed") {
+        g_error = "rtgo_host_render_multi: mode must be path or distributed";
+        return RTGO_E_INVALID;
+    }
+    try {
+        auto scene = std::make_shared<Scene>(model, width, height);
+        MultiGpuRenderer::Options opt;
+        opt.devices.assign(devices, devices + n_devices);
+        opt.launchesPerDevice = launches_per_device > 0 ? launches_per_device : 1;
+        opt.presentEvery = present_every > 0 ? present_every : 1;
+        opt.rcclForLocalShares = rccl_for_local_shares != 0;
+        MultiGpuRenderer renderer(scene, m == "path" ? RenderMode::PATH_TRACING : RenderMode::DISTRIBUTED_RAY_TRACING, sample, ambient != 0, opt);
+        renderer.SetFrames(frames);
+        renderer.Display();
+        if (host_image) {
+            const std::vector<unsigned char> img = renderer.ReadImage();
+            std::memcpy(host_image, img.data(), img.size());
+        }
+        if (host_accum) {
+            const std::vector<float> acc = renderer.ReadAccum();
+            std::memcpy(host_accum, acc.data(), acc.size() * sizeof(float));
+        }
+        if (stats) *stats = renderer.Stats();
+        if (ms_per_frame) *ms_per_frame = renderer.LastDisplayMsPerFrame();
     } catch (const std::exception& e) {
         g_error = e.what();
         return RTGO_E_STATE;

@@ -1,5 +1,6 @@
 // main.cpp -- headless `engine` command: the flags of engine/main.cpp:38-167 (--dim, --mode, --scene, --sample,
 // --useAmbient, --help; --mode and --scene mandatory) plus what a box without a display needs: --frames, --out, --device.
+#include "multigpu.h"
 #include "renderer.h"
 
 #include <cstdlib>
@@ -23,7 +24,10 @@ static void printUsageAndExit(const char* argv0)
               << "         --frames=<K>                Progressive frames to accumulate; default 1   [headless addition]\n"
               << "         --out=<file.ppm>            Write the final 8-bit image (P6)              [headless addition]\n"
               << "         --out-accum=<file.pfm>      Write the float accumulation buffer (PFM)       [headless addition]\n"
-              << "         --device=<i>                GPU index; default 0                          [headless addition]\n";
+              << "         --device=<i>                GPU index; default 0                          [headless addition]\n"
+              << "         --gpus=<n>                  Tile the frame in 4-row bands over GPUs 0..n-1, RCCL gather to GPU 0 [multi-GPU addition]\n"
+              << "         --launches-per-gpu=<1|2>    Shares per GPU; default 2 when n >= 4           [multi-GPU addition]\n"
+              << "         --present-every=<k>         Gather + assemble every k-th frame; default 1   [multi-GPU addition]\n";
     std::exit(1);
 }
 
@@ -41,7 +45,7 @@ static void parseDimensions(const char* arg, int& width, int& height)
 
 int main(int argc, char* argv[])
 {
-    int width = 600, height = 600, sample = 1, frames = 1, device = 0;
+    int width = 600, height = 600, sample = 1, frames = 1, device = 0, gpus = 0, launchesPerGpu = 0, presentEvery = 1;
     bool modeFound = false, sceneFound = false, useAmbient = false;
     RenderMode mode = RenderMode::PATH_TRACING;
     SceneModel scene = SceneModel::CORNELL;
@@ -74,12 +78,31 @@ int main(int argc, char* argv[])
             else if (is("--out-accum=")) outAccum = value("--out-accum=");
             else if (is("--out=")) out = value("--out=");
             else if (is("--device=")) device = std::atoi(value("--device=").c_str());
+            else if (is("--gpus=")) gpus = std::atoi(value("--gpus=").c_str());
+            else if (is("--launches-per-gpu=")) launchesPerGpu = std::atoi(value("--launches-per-gpu=").c_str());
+            else if (is("--present-every=")) presentEvery = std::atoi(value("--present-every=").c_str());
             else { std::cerr << "Unknown option '" << arg << "'\n"; printUsageAndExit(argv[0]); }
         }
         if (!modeFound) { std::cerr << "Argument manquant: --mode=" << std::endl; printUsageAndExit(argv[0]); }
         if (!sceneFound) { std::cerr << "Argument manquant: --scene=" << std::endl; printUsageAndExit(argv[0]); }
 
         auto sc = std::make_shared<engine::host::Scene>(scene, width, height);
+        if (gpus >= 1) {
+            engine::host::MultiGpuRenderer::Options opt;
+            for (int g = 0; g < gpus; ++g) opt.devices.push_back(g);
+            opt.launchesPerDevice = launchesPerGpu > 0 ? launchesPerGpu : (gpus >= 4 ? 2 : 1);
+            opt.presentEvery = presentEvery;
+            engine::host::MultiGpuRenderer renderer(sc, mode, sample, useAmbient, opt);
+            renderer.SetFrames(frames);
+            renderer.SetOutputFile(out);
+            renderer.SetAccumFile(outAccum);
+            renderer.Display();
+            const rtgo_stats st = renderer.Stats();
+            std::cout << "gpus " << gpus << ", shares " << renderer.Shares() << ", frames " << st.launches << ", rays " << st.rays_total
+                      << ", ms/frame (host wall, launch + gather + assemble) " << renderer.LastDisplayMsPerFrame() << ", Mray/s "
+                      << (renderer.LastDisplayMsPerFrame() > 0 ? st.rays_total / (renderer.LastDisplayMsPerFrame() * frames) / 1e3 : 0.0) << std::endl;
+            return 0;
+        }
         engine::host::Renderer renderer(sc, mode, sample, useAmbient);
         renderer.SetDevice(device);
         renderer.SetFrames(frames);

@@ -37,6 +37,10 @@ def load():
         L.rtgo_host_render.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p, C.POINTER(capi.Stats)]
         L.rtgo_host_last_error.restype = C.c_char_p
+        L.rtgo_host_render_multi.restype = C.c_int
+        L.rtgo_host_render_multi.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.POINTER(capi.Stats), C.POINTER(C.c_double)]
         L.rtgo_host_material.restype = C.c_int
         L.rtgo_host_material.argtypes = [C.c_char_p, C.POINTER(C.c_float)]
         _lib = L
@@ -87,6 +91,23 @@ def host_render(name, mode, width, height, sample=1, ambient=False, frames=1, de
     if rc != 0:
         raise capi.RtgoError("rtgo_host_render failed (%d): %s" % (rc, load().rtgo_host_last_error().decode()))
     return acc, img, st.as_dict()
+
+
+def host_render_multi(name, mode, width, height, sample=1, ambient=False, frames=1, devices=(0,), launches_per_device=1,
+                      present_every=1, rccl_for_local_shares=False):
+    """engine::host::MultiGpuRenderer (C++, RCCL gather) headless: returns (accum, image, stats, ms_per_frame)"""
+    L = load()
+    img = np.zeros((height, width, 4), dtype=np.uint8)
+    acc = np.zeros((height, width, 4), dtype=np.float32)
+    st = capi.Stats()
+    ms = C.c_double(0.0)
+    dev = (C.c_int * len(devices))(*devices)
+    rc = L.rtgo_host_render_multi(name.encode(), mode.encode(), width, height, sample, int(ambient), frames, dev, len(devices),
+                                  launches_per_device, present_every, int(rccl_for_local_shares), img.ctypes.data, acc.ctypes.data,
+                                  C.byref(st), C.byref(ms))
+    if rc:
+        raise capi.RtgoError("rtgo_host_render_multi: %s" % L.rtgo_host_last_error().decode())
+    return acc, img, st.as_dict(), ms.value
 
 
 class Session:

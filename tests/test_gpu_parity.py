@@ -99,7 +99,7 @@ def test_all_scenes_small(capi, oracle, name, mode):
     ctx.reset_stats()
     acc, img = gpu_render(capi, ctx, W, H, n, 0, path, amb, stats=True)
     racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, ambient=amb, mode=1))
-    m = assert_parity(acc, racc, img, rimg, min_frac=0.985, what="%s %s" % (name, mode))
+    m = assert_parity(acc, racc, img, rimg, what="%s %s" % (name, mode))
     st = ctx.stats()
     for k, tol in (("rays_total", 0.01), ("node_visits", 0.02), ("prim_tests", 0.02), ("hits", 0.01)):
         assert abs(st[k] - rc[k]) <= tol * max(rc[k], 1), (k, st[k], rc[k])
@@ -196,28 +196,85 @@ def test_config3_balls_1080p_properties(capi, oracle):
     assert_parity(acc[500:590, 900:1060], racc, img[500:590, 900:1060], rimg, what="balls 1080p crop")
 
 
-def test_config4_mirror_spheres_4k_bands_of_8(capi, oracle):
-    """BASELINE config 4 geometry (mirror_spheres 3840x2160, framebuffer tiled over 8 ranks) on one GPU: the 8 band
-    launches reassemble to the whole-image launch bit for bit (N=2 here to keep the test short; N is not part of the tiling)"""
-    W, H, n = 3840, 2160, 2
+def _full_frame_properties(acc, img, st, W, H, n):
+    """size-independent properties of a whole frame (kernel.cu:236-246): finite, alpha 1 / 255, image == make_color(accum),
+    ray-count bounds (N*N primary rays per pixel, at most 6 radiance rays per sample in path mode)"""
+    assert np.isfinite(acc).all() and (acc[..., 3] == 1.0).all() and (img[..., 3] == 255).all()
+    exp = (np.clip(acc[..., :3], 0.0, 1.0) * np.float32(255.0)).astype(np.uint8)
+    assert np.array_equal(exp, img[..., :3])
+    assert n * n * W * H <= st["rays_total"] <= 6 * n * n * W * H
+
+
+def test_config4_mirror_spheres_4k_spp64_bands_of_8(capi, oracle):
+    """BASELINE config 4 at its real size and sample count: mirror_spheres 3840x2160 --sample=8 (64 spp = 4 passes of 16 samples
+    per pixel, kernel.cu:206-246), framebuffer tiled over 8 ranks.  Whole frame: properties + determinism; a 128x72 crop
+    against the oracle; the 8 band launches reassemble to the whole-image launch bit for bit and trace exactly its rays."""
+    W, H, n = 3840, 2160, 8
     sc, t, ctx = upload(capi, oracle, "mirror_spheres", W, H)
+    ctx.reset_stats()
     full, fimg = gpu_render(capi, ctx, W, H, n, 0, True)
-    out = np.zeros_like(full)
-    rays = 0
-    total = ctx.stats()["rays_total"]
+    st = ctx.stats()
+    _full_frame_properties(full, fimg, st, W, H, n)
+    again, _ = gpu_render(capi, ctx, W, H, n, 0, True)
+    assert np.array_equal(again.view(np.uint32), full.view(np.uint32))           # determinism
+    win = (1850, 1040, 128, 72)                                                  # the two spheres and the floor between them
+    racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, window=win, mode=1))
+    x0, y0, w, h = win
+    m = assert_parity(full[y0:y0 + h, x0:x0 + w], racc, fimg[y0:y0 + h, x0:x0 + w], rimg, what="C4 mirror_spheres 4K spp 64 crop")
+    out, oimg = np.zeros_like(full), np.zeros_like(fimg)
     ctx.reset_stats()
     for g in range(8):
-        a, _ = gpu_render(capi, ctx, W, H, n, 0, True, bands=(4, 8, g))
-        out[[r for r in range(H) if (r // 4) % 8 == g]] = a
+        a, i8 = gpu_render(capi, ctx, W, H, n, 0, True, bands=(4, 8, g))
+        rows = [r for r in range(H) if (r // 4) % 8 == g]
+        out[rows], oimg[rows] = a, i8
     assert np.array_equal(out.view(np.uint32), full.view(np.uint32))
-    assert ctx.stats()["rays_total"] == total          # the 8 bands trace exactly the rays of the whole frame
-    win = (1800, 1000, 128, 72)
-    racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, window=win, mode=1))
-    assert_parity(full[1000:1072, 1800:1928], racc, what="mirror_spheres 4K crop")
+    assert np.array_equal(oimg, fimg)
+    assert ctx.stats()["rays_total"] == st["rays_total"]          # the 8 bands trace exactly the rays of the whole frame
+    print("C4", m, st["rays_total"], st["last_launch_ms"])
+    ctx.close()
+
+
+def test_config5_plateau_4k_spp256_progressive_bands_of_8(capi, oracle):
+    """BASELINE config 5 at its real size and sample count: plateau 3840x2160 --sample=16 (256 spp = 16 passes), progressive
+    frames 0 and 1 (running average, kernel.cu:239-245), tiled over 8 ranks whose bands keep their own accumulation rows."""
+    W, H, n = 3840, 2160, 16
+    sc, t, ctx = upload(capi, oracle, "plateau", W, H)
+    ctx.reset_stats()
+    f0, i0 = gpu_render(capi, ctx, W, H, n, 0, True)
+    st0 = ctx.stats()
+    _full_frame_properties(f0, i0, st0, W, H, n)
+    f0 = f0.copy()
+    ctx.reset_stats()
+    f1, i1 = gpu_render(capi, ctx, W, H, n, 1, True)          # accumulates onto frame 0 in place
+    st1 = ctx.stats()
+    _full_frame_properties(f1, i1, st1, W, H, n)
+    win = (1800, 820, 128, 72)                                # cylinders, a sphere, the plate's rim
+    x0, y0, w, h = win
+    r0, ri0, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=True, window=win, mode=1))
+    assert_parity(f0[y0:y0 + h, x0:x0 + w], r0, i0[y0:y0 + h, x0:x0 + w], ri0, what="C5 plateau 4K spp 256 frame 0 crop")
+    r1, ri1, _ = oracle.render(sc, oracle.frame(W, H, n, 1, path=True, window=win, mode=1), accum_prev=r0)
+    m = assert_parity(f1[y0:y0 + h, x0:x0 + w], r1, i1[y0:y0 + h, x0:x0 + w], ri1, what="C5 plateau 4K spp 256 frames 0-1 crop")
+    # 8 ranks, two progressive frames each on its own compact band buffer
+    out0, out1, oimg1 = np.zeros_like(f0), np.zeros_like(f1), np.zeros_like(i1)
+    rays = 0
+    for g in range(8):
+        rows = [r for r in range(H) if (r // 4) % 8 == g]
+        ctx.reset_stats()
+        a0, _ = gpu_render(capi, ctx, W, H, n, 0, True, bands=(4, 8, g))
+        out0[rows] = a0
+        a1, b1 = gpu_render(capi, ctx, W, H, n, 1, True, bands=(4, 8, g))     # onto the band's own frame 0, resident in its buffer
+        out1[rows], oimg1[rows] = a1, b1
+        rays += ctx.stats()["rays_total"]
+    assert np.array_equal(out0.view(np.uint32), f0.view(np.uint32))
+    assert np.array_equal(out1.view(np.uint32), f1.view(np.uint32))
+    assert np.array_equal(oimg1, i1)
+    assert rays == st0["rays_total"] + st1["rays_total"]
+    print("C5", m, st0["rays_total"], st1["rays_total"], st1["last_launch_ms"])
+    ctx.close()
 
 
 def test_config5_plateau_progressive_deep(capi, oracle):
-    """BASELINE config 5 shape (plateau, N=16 = 256 spp, progressive frames) at reduced resolution: 4 accumulated frames"""
+    """the shape of config 5 (plateau, N=16 = 256 spp, progressive frames) as a WHOLE small image: 3 accumulated frames"""
     W, H, n = 96, 54, 16
     sc, t, ctx = upload(capi, oracle, "plateau", W, H)
     racc = None
@@ -240,7 +297,7 @@ def test_host_renderer_end_to_end(capi, oracle):
     assert st["launches"] == 3
     acc2, img2, _ = hscene.host_render("window", "distributed", W, H, sample=1, ambient=True, frames=1)
     r2, i2, _ = oracle.render(oracle.scene("window", W, H), oracle.frame(W, H, 1, 0, path=False, ambient=True, mode=1))
-    assert_parity(acc2, r2, img2, i2, min_frac=0.985, what="host Renderer distributed+ambient")
+    assert_parity(acc2, r2, img2, i2, what="host Renderer distributed+ambient")
 
 
 def test_golden_oracle_renders(capi, oracle):
@@ -252,7 +309,7 @@ def test_golden_oracle_renders(capi, oracle):
         sc, t, ctx = upload(capi, oracle, m["name"], m["W"], m["H"])
         for fr in range(m["frames"]):
             acc, img = gpu_render(capi, ctx, m["W"], m["H"], m["N"], fr, m["path"], m["ambient"])
-        assert_parity(acc, z["accum_%d" % i], img, z["image_%d" % i], min_frac=0.985, what=str(m))
+        assert_parity(acc, z["accum_%d" % i], img, z["image_%d" % i], what=str(m))
         ctx.close()
 
 
@@ -325,7 +382,7 @@ def test_random_scenes_through_the_plugin_surface(capi, oracle, seed):
         racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, ambient=amb, mode=1))
         r0, _, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, ambient=amb, mode=0))
         assert np.array_equal(r0.view(np.uint32), racc.view(np.uint32)), "oracle literal != oracle LBVH"
-        assert_parity(acc, racc, img, rimg, min_frac=0.98, what="random scene %d %s" % (seed, (path, amb)))
+        assert_parity(acc, racc, img, rimg, what="random scene %d %s" % (seed, (path, amb)))
         fast, fimg = gpu_render(capi, ctx, W, H, n, 0, path, amb, stats=False)
         assert np.array_equal(fast.view(np.uint32), acc.view(np.uint32)), "fast walk != canonical walk"
     ctx.close()
@@ -412,14 +469,15 @@ def test_shallower_trace_depths(capi, oracle, max_depth):
         rows = H
         if ctx.pixels < W * H:
             ctx.resize(W * H)
+        ctx.reset_stats()
         ctx.launch(capi.make_frame(W, H, 2, 0, path, False, None, (4, 1, 0), max_depth=max_depth))
         ctx.sync()
         acc, img = ctx.read_accum(H, W), ctx.read_image(H, W)
         racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, 2, 0, path=path, mode=1, max_depth=max_depth))
         assert_parity(acc, racc, img, rimg, what="max_depth %d path=%s" % (max_depth, path))
         if path and max_depth == 0:
-            # no bounce at all: only primary rays, and only emitters are visible
-            assert ctx.stats()["rays_total"] % (W * H * 4) == 0 or True
+            # no bounce at all: exactly the N*N primary rays of every pixel, and only emitters are visible
+            assert rc["rays_total"] == W * H * 4 and ctx.stats()["rays_total"] == W * H * 4
     ctx.close()
 
 
@@ -437,7 +495,7 @@ def test_camera_inside_the_scene(capi, oracle):
     for path in (True, False):
         acc, img = gpu_render(capi, ctx, W, H, n, 0, path)
         racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
-        assert_parity(acc, racc, img, rimg, min_frac=0.985, what="camera inside, path=%s" % path)
+        assert_parity(acc, racc, img, rimg, what="camera inside, path=%s" % path)
         canon, _ = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
         assert np.array_equal(canon.view(np.uint32), acc.view(np.uint32))
     ctx.close()
@@ -449,7 +507,7 @@ def test_odd_sample_counts_and_tiny_images(capi, oracle):
         sc, t, ctx = upload(capi, oracle, "mirror_spheres", W, H)
         acc, img = gpu_render(capi, ctx, W, H, n, 2, True, prev=np.full((H, W, 4), 0.5, np.float32))
         racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 2, path=True, mode=1), accum_prev=np.full((H, W, 4), 0.5, np.float32))
-        assert_parity(acc, racc, img, rimg, min_frac=0.97 if W * H < 100 else 0.99, what="%dx%d N=%d" % (W, H, n))
+        assert_parity(acc, racc, img, rimg, what="%dx%d N=%d" % (W, H, n))
         assert ctx.stats()["rays_total"] == rc["rays_total"] or abs(ctx.stats()["rays_total"] - rc["rays_total"]) <= 0.01 * rc["rays_total"]
         ctx.close()
 
@@ -583,7 +641,7 @@ def test_paired_rectangles_in_boxes(capi, oracle, case):
         assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), "fast walk != canonical walk"
         assert np.array_equal(fimg, cimg)
         racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 1, path=path, ambient=amb, mode=1), accum_prev=prev)
-        assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="boxes %s path=%s" % (case, path))
+        assert_parity(canon, racc, cimg, rimg, what="boxes %s path=%s" % (case, path))
     ctx.close()
 
 
@@ -632,7 +690,7 @@ def test_far_camera_where_the_sphere_quadratic_loses_its_digits(capi, oracle):
             canon, cimg = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
             assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), (eye, path)
             racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
-            assert_parity(canon, racc, cimg, rimg, min_frac=0.99, what="far camera path=%s" % path)
+            assert_parity(canon, racc, cimg, rimg, what="far camera path=%s" % path)
     ctx.close()
 
 
@@ -678,7 +736,7 @@ def test_smallest_and_largest_scenes(capi, oracle):
             fast, fimg = gpu_render(capi, ctx, W, H, n, 0, path)
             assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), (len(types), path)
             racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
-            assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="%d primitives path=%s" % (len(types), path))
+            assert_parity(canon, racc, cimg, rimg, what="%d primitives path=%s" % (len(types), path))
             assert abs(st["rays_total"] - rc["rays_total"]) <= 0.01 * rc["rays_total"]
         ctx.close()
 
@@ -705,7 +763,7 @@ def test_rays_with_an_exactly_zero_direction_component(capi, oracle, name):
             canon, cimg = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
             assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), (name, axis, path)
             racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
-            assert_parity(canon, racc, cimg, rimg, min_frac=0.98, what="%s zero component %d path=%s" % (name, axis, path))
+            assert_parity(canon, racc, cimg, rimg, what="%s zero component %d path=%s" % (name, axis, path))
     ctx.close()
 
 
@@ -727,3 +785,56 @@ def test_both_walks_agree_on_every_ray(tmp_path):
     last = [l for l in r.stdout.splitlines() if l.startswith("total:")][-1]
     rays, bad = int(last.split()[1]), int(last.split()[3])
     assert rays > 100_000_000 and bad == 0, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rccl_local", [False, True])
+def test_cpp_multigpu_driver_two_shares_on_one_gpu(capi, oracle, rccl_local):
+    """engine::host::MultiGpuRenderer (C++ host, raytracingo_amd/host/multigpu.cpp) on a one-GPU box: two shares of the band
+    interleave on GPU 0, each with its own context, stream and resident accumulation bands; the 8-bit bands are gathered to the
+    root every frame -- by device-to-device copies, or (rccl_local) through RCCL's grouped ncclSend/ncclRecv on a one-rank
+    communicator -- and assembled by rtgo_assemble_bands.  The presented frame and the gathered accumulation buffer must equal
+    the single-launch Renderer's bit for bit (pixels are independent: kernel.cu:187-217), and the oracle's within tolerance."""
+    from raytracingo_amd import scene as hscene
+    W, H, n, frames = 200, 90, 2, 3        # 90 rows: 23 bands of 4 rows over 2 shares, the last band 2 rows high
+    acc1, img1, st1 = hscene.host_render("mirror_spheres", "path", W, H, sample=n, frames=frames)
+    acc2, img2, st2, ms = hscene.host_render_multi("mirror_spheres", "path", W, H, sample=n, frames=frames, devices=(0,),
+                                                   launches_per_device=2, present_every=1, rccl_for_local_shares=rccl_local)
+    assert np.array_equal(img2, img1)
+    assert np.array_equal(acc2.view(np.uint32), acc1.view(np.uint32))
+    assert st2["rays_total"] == st1["rays_total"] and st2["launches"] == frames
+    # a frame that is not presented is still accumulated: present only the last of the three
+    acc3, img3, _, _ = hscene.host_render_multi("mirror_spheres", "path", W, H, sample=n, frames=frames, devices=(0,),
+                                                launches_per_device=2, present_every=5, rccl_for_local_shares=rccl_local)
+    assert np.array_equal(img3, img1) and np.array_equal(acc3.view(np.uint32), acc1.view(np.uint32))
+    sc = oracle.scene("mirror_spheres", W, H)
+    racc = None
+    for f in range(frames):
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, f, path=True, mode=1), accum_prev=racc)
+    assert_parity(acc2, racc, img2, rimg, what="C++ multi-GPU driver")
+    print("multi-GPU driver, 2 shares on one GPU, rccl_local=%s: %.3f ms/frame host wall" % (rccl_local, ms))
+
+
+@pytest.mark.gpu
+def test_assemble_bands_odd_shapes(capi):
+    """rtgo_assemble_bands against numpy for widths that force the 4-byte path, band heights 1..5 and 1..7 ranks"""
+    import torch
+    ctx = capi.Context(0)
+    L = capi.load()
+    rng = np.random.default_rng(5)
+    for (w, h, band_h, G, elem) in [(37, 19, 4, 3, 4), (64, 64, 4, 8, 4), (5, 7, 1, 7, 16), (130, 33, 5, 2, 4), (3, 2, 4, 1, 16), (21, 40, 3, 4, 16)]:
+        rows = [[r for r in range(h) if (r // band_h) % G == g] for g in range(G)]
+        rows_pad = max(len(r) for r in rows) + 1
+        full = rng.integers(0, 255, size=(h, w * elem), dtype=np.uint8)
+        gathered = np.zeros((G * rows_pad, w * elem), dtype=np.uint8)
+        for g in range(G):
+            gathered[g * rows_pad:g * rows_pad + len(rows[g])] = full[rows[g]]
+        d_g = torch.from_numpy(gathered).cuda()
+        d_f = torch.zeros((h, w * elem), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rc = L.rtgo_assemble_bands(ctx._h, None, d_g.data_ptr(), d_f.data_ptr(), w, h, band_h, G, rows_pad, elem)
+        assert rc == 0
+        ctx.sync()
+        assert np.array_equal(d_f.cpu().numpy(), full), (w, h, band_h, G, elem)
+    assert L.rtgo_assemble_bands(ctx._h, None, d_g.data_ptr(), d_f.data_ptr(), 21, 40, 3, 4, 2, 16) != 0   # rows_pad too small
+    ctx.close()
