@@ -81,8 +81,8 @@ struct RenderKernelEntry {
     RenderKernel fn;
 };
 static const RenderKernelEntry kRenderKernels[] = {
-    {true, false, 4, render_kernel<true, false, 4>},   {true, false, 5, render_kernel<true, false, 5>},   {true, false, 6, render_kernel<true, false, 6>},
-    {false, false, 4, render_kernel<false, false, 4>}, {false, false, 5, render_kernel<false, false, 5>}, {false, false, 6, render_kernel<false, false, 6>},
+    {true, false, 4, render_kernel<true, false, 4>},   {true, false, 5, render_kernel<true, false, 5>},
+    {false, false, 4, render_kernel<false, false, 4>}, {false, false, 5, render_kernel<false, false, 5>},
     {true, true, 4, render_kernel<true, true, 4>},     {false, true, 4, render_kernel<false, true, 4>},
 };
 static RenderKernel find_kernel(bool path, bool canon, int wpe)
@@ -589,18 +589,19 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
                              (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float);   // + the raygen constants
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
     size_t lds = 0;
-    // Waves per SIMD the kernel variant is compiled for: 4 (<= 128 VGPRs), 5 (<= 96, level records in LDS), 6 (<= 80, some spills).
-    // (A 7-waves variant, <= 72 VGPRs, bought 0.8 % on cornell and doubled the spill traffic, 556 -> 1135 MB per launch: dropped.)
-    // More resident waves fill more of the vector issue slots (cornell 1080p: 1.285 ms at 5, 1.235 at 6), but every wave then
-    // runs slower and the launch ends one unit-duration after the queue runs dry: with few units per wave the shorter tail
-    // of fewer waves wins (a 1/16 share: 0.127 / 0.137 / 0.162 ms at 4 / 5 / 6).
+    // Waves per SIMD the kernel variant is compiled for: 4 (<= 128 VGPRs) or 5 (<= 96, level records in LDS; 1-2 spilled dwords).
+    // More resident waves fill more of the vector issue slots (cornell 1080p: 1.32 ms at 4, 1.22 at 5), but every wave then runs
+    // slower and the launch ends one unit-duration after the queue runs dry: with few units per wave the shorter tail of fewer
+    // waves wins (a 1/16 share: 0.127 / 0.137 ms at 4 / 5).  A 6-waves variant (<= 80 VGPRs) ran 1 % faster still (1.209 ms) but
+    // spilled 25-32 registers to scratch -- 472 MB of HBM traffic per launch against 94 MB at 5 waves and 74.6 MB of framebuffer
+    // (profiles/r02c) -- and was dropped: the kernel should not pay HBM for registers.
     const uint64_t units_per_wave4 = units_hot * (passes_of(nn)) / ((uint64_t)c->num_cus * 16u);
-    const int max_wpe_work = units_per_wave4 >= 12 ? 6 : (units_per_wave4 >= 3 ? 5 : 4);
+    const int max_wpe_work = units_per_wave4 >= 3 ? 5 : 4;
     int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);   // (experiment knob, clamped to what exists)
-    max_wpe = max_wpe < 4 ? 4 : (max_wpe > 6 ? 6 : max_wpe);
+    max_wpe = max_wpe < 4 ? 4 : (max_wpe > 5 ? 5 : max_wpe);
     for (int w = 4; w <= max_wpe; ++w)
         for (int b = 256; b <= kMaxBlock; b *= 2) {
-            const size_t l = scene_lds + (size_t)p.stack_depth * b * sizeof(float2) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
+            const size_t l = scene_lds + (size_t)p.stack_depth * b * (canon ? sizeof(float2) : sizeof(unsigned int)) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
             int per_cu = (int)((160 * 1024) / l);
             if (per_cu * (b / 64) > 4 * w) per_cu = (4 * w) / (b / 64);
             const int waves = per_cu * (b / 64);

@@ -371,14 +371,39 @@ __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, 
 // =====================================================================================================================
 struct FastHit {
     float t;
-    v3 nobj;   // object-space normal of the winner (kernel.cu:270,315,345,388 before TransformNormal)
-    int pos;   // Morton position of the winner
+    v3 nobj;   // object-space normal of the winner when it is a sphere or a cylinder (kernel.cu:270,315 before TransformNormal)
+    int pos;   // Morton position of the winner | kFlat when it is a rectangle or a disk (object-space normal (0,1,0): kernel.cu:345,388)
     int orig;  // its SBT index (tie-break + material lookup)
 };
+constexpr int kFlat = 0x10000;
 
+// the acceptance rule of SURVEY a14 (tmin < t < current closest; ties keep the lower SBT index), without branches
 __device__ __forceinline__ bool closer(float t, int orig, float tmin, const FastHit& best)
 {
-    return t > tmin && (t < best.t || (t == best.t && best.orig >= 0 && orig < best.orig));
+    return (t > tmin) & ((t < best.t) | ((t == best.t) & (best.orig >= 0) & (orig < best.orig)));
+}
+
+// __intersection__rectangle (kernel.cu:372-416) on M^-1 rows, as straight-line code: every lane evaluates the whole test and the
+// result is committed through selects.  The lanes of a wave carry unrelated rays once paths have bounced, so some lane needs every
+// stage of the test anyway; nesting the stages in branches then only adds exec-mask bookkeeping and idle lanes.  `facing` (d.y < 0 in
+// object space, evaluated by the caller) and the other conditions of the reference enter as predicates.
+template <typename Ptr>
+__device__ __forceinline__ void rect_commit(Ptr rec, const float4 r1, float dy, bool facing, int pos, int orig, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+    const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
+    // oy > 0 with d.y < 0 is the only way to t > 0 (so d.y != 0 and t > 1e-4 can hold); lanes that fail carry garbage in t
+    const float t = (0.0f - oy) / dy;
+    bool c = facing & (oy > 0.0f) & (t > 0.0001f) & closer(t, orig, tmin, best);
+    if (__ballot(c) == 0ull) return;   // (coherent waves -- primary rays -- often leave here together)
+    const float4 r0 = rec[0], r2 = rec[2];
+    const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
+    const float ox = r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, oz = r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w;
+    const float px = ox + t * dx, pz = oz + t * dz;
+    const float u = px + 0.5f, v = -(pz - 0.5f);
+    c = c & (0.0f < u) & (u < 1.0f) & (0.0f < v) & (v < 1.0f);
+    best.t = c ? t : best.t;
+    best.pos = c ? (pos | kFlat) : best.pos;
+    best.orig = c ? orig : best.orig;
 }
 
 template <typename Ptr>
@@ -389,25 +414,7 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
     const int type = __float_as_int(meta.x), orig = __float_as_int(meta.y);
     if (type == 2) {  // rectangle
         const float dy = r1.x * wd.x + r1.y * wd.y + r1.z * wd.z;
-        if (dy < 0.0f) {
-            const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
-            if (oy > 0.0f) {
-                const float t = (0.0f - oy) / dy;
-                if (t > 0.0001f && closer(t, orig, tmin, best)) {
-                    const float4 r0 = s_fprims[4 * pos + 0], r2 = s_fprims[4 * pos + 2];
-                    const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
-                    const float ox = r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, oz = r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w;
-                    const float px = ox + t * dx, pz = oz + t * dz;
-                    const float u = px + 0.5f, v = -(pz - 0.5f);
-                    if (0.0f < u && u < 1.0f && 0.0f < v && v < 1.0f) {
-                        best.t = t;
-                        best.nobj = mk(0.0f, 1.0f, 0.0f);
-                        best.pos = pos;
-                        best.orig = orig;
-                    }
-                }
-            }
-        }
+        rect_commit(s_fprims + 4 * pos, r1, dy, dy < 0.0f, pos, orig, wo, wd, tmin, best);
         return;
     }
     const float4 r0 = s_fprims[4 * pos + 0], r2 = s_fprims[4 * pos + 2];
@@ -468,8 +475,7 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
                 const v3 p = vadd(o, vscale(d, t));
                 if (vdot(p, p) < 1.0f) {
                     best.t = t;
-                    best.nobj = mk(0.0f, 1.0f, 0.0f);
-                    best.pos = pos;
+                    best.pos = pos | kFlat;
                     best.orig = orig;
                 }
             }
@@ -480,8 +486,8 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
 // Two rectangles that the build has put side by side because their normals are opposite (the two faces of a box, floor and
 // ceiling, left and right wall).  A rectangle is one-sided: its test starts with d.y < 0 in object space (kernel.cu:394-400),
 // and d.y is the ray direction against the world normal, so at most one of the two can get past that first test -- the
-// rest of the test then runs once, on whichever it is, instead of twice with half of the lanes masked off.  Exactly the
-// tests leaf_test() would make, on the same values: when rounding lets BOTH through, both are tested.
+// rest of the test then runs once, on whichever it is, instead of twice.  Exactly the tests leaf_test() would make, on the same
+// values: when rounding lets BOTH through (a wave-level vote; rare), those lanes run both.
 template <bool LIST, typename Ptr>
 __device__ __forceinline__ void pair_test(Ptr fp, const float4* __restrict__ lds, int pos, v3 wo, v3 wd, float tmin, FastHit& best)
 {
@@ -492,35 +498,16 @@ __device__ __forceinline__ void pair_test(Ptr fp, const float4* __restrict__ lds
     const float dya = r1a.x * wd.x + r1a.y * wd.y + r1a.z * wd.z;
     const float dyb = r1b.x * wd.x + r1b.y * wd.y + r1b.z * wd.z;
     const bool fa = dya < 0.0f, fb = dyb < 0.0f;
-    if (fa && fb) {
-        leaf_test(fp, pos, wo, wd, tmin, best);
-        leaf_test(fp, pos + 1, wo, wd, tmin, best);
-        return;
-    }
-    if (fa || fb) {
-        const int sel = fa ? pos : pos + 1;
-        // (rows already in VGPRs are chosen by four selects; rows in SGPRs would take twelve instructions: re-read the row instead)
-        const float4 r1 = LIST ? lds[4 * sel + 1] : make_float4(fa ? r1a.x : r1b.x, fa ? r1a.y : r1b.y, fa ? r1a.z : r1b.z, fa ? r1a.w : r1b.w);
-        const float dy = fa ? dya : dyb;
-        const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
-        if (oy > 0.0f) {
-            const float t = (0.0f - oy) / dy;
-            const int orig = __float_as_int(lds[4 * sel + 3].y);
-            if (t > 0.0001f && closer(t, orig, tmin, best)) {
-                const float4 r0 = lds[4 * sel + 0], r2 = lds[4 * sel + 2];
-                const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
-                const float ox = r0.x * wo.x + r0.y * wo.y + r0.z * wo.z + r0.w, oz = r2.x * wo.x + r2.y * wo.y + r2.z * wo.z + r2.w;
-                const float px = ox + t * dx, pz = oz + t * dz;
-                const float u = px + 0.5f, v = -(pz - 0.5f);
-                if (0.0f < u && u < 1.0f && 0.0f < v && v < 1.0f) {
-                    best.t = t;
-                    best.nobj = mk(0.0f, 1.0f, 0.0f);
-                    best.pos = sel;
-                    best.orig = orig;
-                }
-            }
+    if (__ballot(fa & fb) != 0ull) {
+        if (fa & fb) {
+            leaf_test(lds, pos, wo, wd, tmin, best);
+            leaf_test(lds, pos + 1, wo, wd, tmin, best);
         }
     }
+    const int sel = fa ? pos : pos + 1;
+    const float4 r1 = LIST ? lds[4 * sel + 1] : make_float4(fa ? r1a.x : r1b.x, fa ? r1a.y : r1b.y, fa ? r1a.z : r1b.z, fa ? r1a.w : r1b.w);
+    const int orig = __float_as_int(lds[4 * sel + 3].y);
+    rect_commit(lds + 4 * sel, r1, fa ? dya : dyb, fa != fb, sel, orig, wo, wd, tmin, best);
 }
 
 // the records [first, first + cnt) of one leaf (or of the up-front list): npairs pairs first, then single primitives
@@ -558,7 +545,7 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 }
 
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 const float4* __restrict__ g_fprims, float2* __restrict__ s_stack, int bshift,
+                                                 const float4* __restrict__ g_fprims, unsigned int* __restrict__ s_stack, int bshift,
                                                  int n_small, int n_prims, int n_big_pairs, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests
 #ifdef RTGO_TIMELINE
@@ -607,12 +594,14 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     }
     int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
     int sp = 0;
+    // A stack entry is ONE word: the far child's entry distance cut to its upper 16 bits (toward zero: a lower bound of a
+    // positive number, so culling at pop time stays conservative) | its node index (< 2 * kMaxPrims).
     auto pop = [&]() -> bool {
         while (sp > 0) {
             --sp;
-            const float2 e = s_stack[sp << bshift];
-            if (e.x <= best.t) {
-                const int idx = __float_as_int(e.y);
+            const unsigned int e = s_stack[sp << bshift];
+            if (__uint_as_float(e & 0xFFFF0000u) <= best.t) {
+                const int idx = (int)(e & 0xFFFFu);
                 left = __float_as_int(s_fnodes[2 * idx].w);
                 right = __float_as_int(s_fnodes[2 * idx + 1].w);
                 return true;
@@ -630,18 +619,16 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
 #endif
             const bool hl = box_fast(l0, l1, id, noid, tmin, best.t, tl);
             const bool hr = box_fast(h0, h1, id, noid, tmin, best.t, tr);
-            if (hl && hr) {
-                const bool swap = tr < tl;
-                s_stack[sp << bshift] = make_float2(swap ? tl : tr, __int_as_float(swap ? left : right));
+            // the step as selects: go to the right child when only it is hit, or when both are and it is nearer; the other one
+            // of two hit children waits on the stack
+            const bool go_r = hr & (!hl | (tr < tl));
+            if (hl & hr) {
+                s_stack[sp << bshift] = (__float_as_uint(go_r ? tl : tr) & 0xFFFF0000u) | (unsigned int)(go_r ? left : right);
                 ++sp;
-                left = __float_as_int(swap ? h0.w : l0.w);
-                right = __float_as_int(swap ? h1.w : l1.w);
-            } else if (hl) {
-                left = __float_as_int(l0.w);
-                right = __float_as_int(l1.w);
-            } else if (hr) {
-                left = __float_as_int(h0.w);
-                right = __float_as_int(h1.w);
+            }
+            if (hl | hr) {
+                left = __float_as_int(go_r ? h0.w : l0.w);
+                right = __float_as_int(go_r ? h1.w : l1.w);
             } else {
                 have = pop();
             }
@@ -659,9 +646,11 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     tl_tree += wall_clock64() + (best.pos == 12345 ? 1 : 0) - tl_s1;
 #endif
     if (best.pos < 0) return false;
-    const float4 r0 = s_fprims[4 * best.pos + 0], r1 = s_fprims[4 * best.pos + 1], r2 = s_fprims[4 * best.pos + 2];
+    const int wpos = best.pos & (kFlat - 1);
+    const bool flat = (best.pos & kFlat) != 0;
+    const float4 r0 = s_fprims[4 * wpos + 0], r1 = s_fprims[4 * wpos + 1], r2 = s_fprims[4 * wpos + 2];
     out.t = best.t;
-    out.n = xf_normal(r0, r1, r2, best.nobj);
+    out.n = xf_normal(r0, r1, r2, flat ? mk(0.0f, 1.0f, 0.0f) : best.nobj);
     out.prim = best.orig;
     return true;
 }
@@ -794,14 +783,14 @@ __device__ __forceinline__ void cold_segment(const LaunchParams& p, unsigned int
 // the V/T/h counters that define the roofline's algorithmic bytes; both produce the same pixels bit for bit.
 // =====================================================================================================================
 // WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs) for scenes whose LDS image limits a CU to 16 waves
-// anyway, 5 (<= 96 VGPRs) and 6 (<= 80 VGPRs) for small scenes, where the extra waves buy more than the tighter budget costs
-// (rtgo_capi.hip picks per launch; kRenderKernels there lists every instantiation).
+// anyway, 5 (<= 96 VGPRs, per-level path records in LDS) for small scenes, where the fifth wave buys more than the tighter
+// budget costs (rtgo_capi.hip picks per launch; kRenderKernels there lists every instantiation).
 template <bool PATH, bool STATS, int WPE>
 __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
-    //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][stack][lights]
+    //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][stack, 4 B/entry][lights]
     constexpr int MS = STATS ? 6 : 3;  // float4 stride between two primitives' material rows (kd|spec, kr|type, Le)
     const int n_nodes = STATS ? p.n_nodes : (p.n_small > 0 ? 2 * p.n_small - 1 : 0);
     float4* s_nodes = reinterpret_cast<float4*>(smem);
@@ -812,7 +801,8 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     const int stack_depth = STATS ? kStackDepth : p.stack_depth;
     const int kBlock = (int)blockDim.x;           // 256, 512 or 1024
     const int bshift = 31 - __clz(kBlock);        // per-lane stack entry e lives at [e << bshift]
-    LightRec* s_lights = reinterpret_cast<LightRec*>(s_stack_base + stack_depth * kBlock);
+    // (entries x workgroup size x 8 bytes for the canonical walk, x 4 for the fast walk's packed words: a multiple of 1 KiB either way)
+    LightRec* s_lights = reinterpret_cast<LightRec*>(reinterpret_cast<unsigned char*>(s_stack_base) + (size_t)stack_depth * kBlock * (STATS ? 8 : 4));
     const float4* s_mat = s_mat_w;
     // small scenes (the 5-waves-per-SIMD variant): per-level path records live in LDS, [4 words x kMaxLevels][lane], instead of
     // 15-20 VGPRs -- that is what lets the allocation fit 96 registers without spilling to scratch
@@ -856,7 +846,8 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 #ifdef RTGO_TIMELINE
     tl_t1 = wall_clock64();
 #endif
-    float2* s_stack = s_stack_base + tid;
+    float2* s_stack = s_stack_base + tid;                                                 // canonical walk: (distance, node) entries
+    unsigned int* s_stack4 = reinterpret_cast<unsigned int*>(s_stack_base) + tid;         // fast walk: one packed word per entry
     const int lane = tid & 63;
     const unsigned int nn = (unsigned int)(p.sqrt_spp * p.sqrt_spp);
     // Work decomposition: ONE LANE = ONE PATH.  A wave takes "units" of 64/nn_eff neighbouring pixels of a row and runs
@@ -1014,7 +1005,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                 c_rays += 1;
                 bool hit;
                 if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack, bshift, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, h, c_nodes, c_tests
+                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack4, bshift, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, h, c_nodes, c_tests
 #ifdef RTGO_TIMELINE
                                             , tl_big, tl_tree
 #endif
@@ -1026,7 +1017,8 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                     // diagnostic build (tools/cmp_walks.py): the fast walk on the same ray, straight from global memory
                     Hit hf;
                     unsigned int d0 = 0, d1 = 0;
-                    const bool hitf = closest_hit_fast(p.fnodes, p.fprims, p.fprims, s_stack, bshift, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, hf, d0, d1);
+                    // (this lane's canonical stack is idle here: its own 8-byte slots serve as the fast walk's one-word entries)
+                    const bool hitf = closest_hit_fast(p.fnodes, p.fprims, p.fprims, reinterpret_cast<unsigned int*>(s_stack), bshift + 1, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, hf, d0, d1);
                     const bool same = hit == hitf && (!hit || (h.t == hf.t && h.prim == hf.prim && h.n.x == hf.n.x && h.n.y == hf.n.y && h.n.z == hf.n.z));
                     if (!same) {
                         const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(p.cmp), 1u);
