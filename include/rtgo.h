@@ -177,6 +177,45 @@ int rtgo_read_bvh(rtgo_ctx* ctx, void* host_nodes, size_t node_bytes, void* host
 int rtgo_assemble_bands(rtgo_ctx* ctx, void* hip_stream, const void* d_gathered, void* d_full, uint32_t w, uint32_t h,
                         uint32_t band_h, uint32_t n_ranks, uint32_t rows_pad, uint32_t elem_bytes);
 
+/* ---- the "whitted" triangle path: cuda/whitted.cu + the mesh side of sutil/Scene.cpp, without textures or glTF loading ----------
+   One launch = one subframe of whitted.cu's pipeline: __raygen__pinhole (tea<4> seed, sub-pixel jitter from subframe 1 on, running
+   average, gamma-2.2 image), __closesthit__radiance (GGX / Smith / Schlick direct lighting of point lights, one occlusion ray per
+   light), __closesthit__occlusion, __miss__constant_radiance.  Camera and output buffers are the context's (rtgo_set_camera,
+   rtgo_resize / rtgo_bind_output, rtgo_read_image / rtgo_read_accum). */
+#define RTGO_MAX_TRIANGLES 4096
+
+/* MaterialData::Pbr (cuda/MaterialData.h:43-52) without its three texture handles */
+typedef struct rtgo_pbr {
+    float base_color[4];
+    float metallic;
+    float roughness;
+} rtgo_pbr;
+
+/* Light::Point (cuda/Light.h:47-53) */
+typedef struct rtgo_point_light {
+    float color[3];
+    float intensity;
+    float position[3];
+    int32_t falloff;   /* Light::Falloff; whitted.cu never reads it */
+} rtgo_point_light;
+
+/* sutil::Scene::addMesh + buildMeshAccels (sutil/Scene.cpp): one triangle mesh in world space = GeometryData::TriangleMesh
+   (cuda/GeometryData.h:46-52; positions and optional vertex normals, 3 floats per vertex; 32-bit indices, 3 per triangle) with
+   one material per triangle (material_of_triangle may be NULL: material 0).  Builds the triangle LBVH on the device.
+   n_triangles <= RTGO_MAX_TRIANGLES.  Synchronous. */
+int rtgo_whitted_set_mesh(rtgo_ctx* ctx, const float* positions, const float* normals, uint32_t n_vertices, const uint32_t* indices,
+                          const uint32_t* material_of_triangle, uint32_t n_triangles, const rtgo_pbr* materials, uint32_t n_materials);
+
+/* whitted::LaunchParams::lights (cuda/whitted.h:71); n <= RTGO_MAX_LIGHTS */
+int rtgo_whitted_set_lights(rtgo_ctx* ctx, const rtgo_point_light* lights, uint32_t n);
+
+/* whitted::LaunchParams::miss_color (cuda/whitted.h:72) */
+int rtgo_whitted_set_miss_color(rtgo_ctx* ctx, const float rgb[3]);
+
+/* optixLaunch of the whitted pipeline over width x height pixels for subframe `subframe_index` (whitted::LaunchParams,
+   cuda/whitted.h:59-74).  Asynchronous on the context's stream; rays are added to rtgo_stats (rays_total, rays_occlusion). */
+int rtgo_whitted_launch(rtgo_ctx* ctx, uint32_t width, uint32_t height, uint32_t subframe_index);
+
 /* number of window rows a rank owns under the band interleave (pure host arithmetic) */
 uint32_t rtgo_local_rows(uint32_t h, uint32_t band_h, uint32_t n_ranks, uint32_t rank);
 

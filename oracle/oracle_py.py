@@ -57,11 +57,18 @@ class Node(C.Structure):
     _fields_ = [("bmin", C.c_float * 3), ("bmax", C.c_float * 3), ("left", C.c_int32), ("right", C.c_int32)]
 
 
+class WhittedScene(C.Structure):
+    _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("indices", C.c_void_p), ("tri_material", C.c_void_p),
+                ("materials", C.c_void_p), ("lights", C.c_void_p), ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("eye", C.c_float * 3), ("U", C.c_float * 3),
+                ("V", C.c_float * 3), ("W", C.c_float * 3), ("miss", C.c_float * 3)]
+
+
 def build(force=False):
     """Compile the oracle (and the reference probe when /root/reference is mounted). Building the checker is not using it."""
     if force or not os.path.exists(LIB_PATH) or any(
             os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
-            for f in ("rtgo_oracle.c", "rtgo_oracle_scenes.c", "rtgo_oracle.h")):
+            for f in ("rtgo_oracle.c", "rtgo_oracle_scenes.c", "rtgo_oracle_whitted.c", "rtgo_oracle.h")):
         subprocess.check_call(["make", "-C", HERE, "-s", "all"])
     return LIB_PATH
 
@@ -101,6 +108,13 @@ def lib():
         L.oracle_hemisphere.argtypes = [fp, fp, C.c_float, u32p, fp]
         L.oracle_scene_create.restype = C.c_int
         L.oracle_scene_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.POINTER(Scene)]
+        L.oracle_tea4.restype = C.c_uint32
+        L.oracle_tea4.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_tri_intersect.restype = C.c_int
+        L.oracle_tri_intersect.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, fp]
+        L.oracle_whitted_render.restype = C.c_int
+        L.oracle_whitted_render.argtypes = [C.POINTER(WhittedScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.POINTER(C.c_uint64), C.c_int]
         L.oracle_material.restype = C.c_int
         L.oracle_material.argtypes = [C.c_char_p, fp]
         L.oracle_lbvh_build.restype = C.c_int
@@ -228,3 +242,33 @@ def light_from_matrix(M, color=(1.0, 1.0, 1.0), falloff=0.0):
     L = Light()
     lib().oracle_light_from_matrix(fptr(f32(M).reshape(16).copy()), fptr(f32(color)), float(falloff), C.byref(L))
     return np.array(list(L.corner) + list(L.v1) + list(L.v2) + list(L.normal) + list(L.color) + [L.falloff], dtype=np.float32)
+
+
+def whitted_render(mesh, cam12, width, height, subframes=1, threads=0):
+    """the oracle's whitted path (rtgo_oracle_whitted.c) over `subframes` accumulated subframes.
+    mesh: dict(positions [nv,3] f32, normals [nv,3] f32 or None, indices [nt,3] u32, tri_material [nt] u32 or None,
+    materials [nm,6] f32 (base_color rgba, metallic, roughness), lights [nl,8] (color rgb, intensity, position xyz, falloff as int bits),
+    miss (3,)).  Returns (accum [h,w,4] f32, image [h,w,4] u8, {rays_total, rays_occlusion})."""
+    pos = np.ascontiguousarray(mesh["positions"], dtype=np.float32)
+    nrm = None if mesh.get("normals") is None else np.ascontiguousarray(mesh["normals"], dtype=np.float32)
+    idx = np.ascontiguousarray(mesh["indices"], dtype=np.uint32)
+    tm = None if mesh.get("tri_material") is None else np.ascontiguousarray(mesh["tri_material"], dtype=np.uint32)
+    mats = np.ascontiguousarray(mesh["materials"], dtype=np.float32)
+    lights = np.ascontiguousarray(mesh["lights"], dtype=np.float32).reshape(-1, 8)
+    s = WhittedScene()
+    s.positions, s.normals = pos.ctypes.data, (nrm.ctypes.data if nrm is not None else None)
+    s.indices, s.tri_material = idx.ctypes.data, (tm.ctypes.data if tm is not None else None)
+    s.materials, s.lights = mats.ctypes.data, (lights.ctypes.data if len(lights) else None)
+    s.n_vertices, s.n_triangles, s.n_materials, s.n_lights = len(pos), len(idx), len(mats), len(lights)
+    cam = f32(cam12)
+    s.eye[:], s.U[:], s.V[:], s.W[:] = cam[0:3].tolist(), cam[3:6].tolist(), cam[6:9].tolist(), cam[9:12].tolist()
+    s.miss[:] = f32(mesh["miss"]).tolist()
+    acc = np.zeros((height, width, 4), dtype=np.float32)
+    img = np.zeros((height, width, 4), dtype=np.uint8)
+    rays = (C.c_uint64 * 2)(0, 0)
+    if threads <= 0:
+        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 1
+    for sf in range(subframes):
+        rc = lib().oracle_whitted_render(C.byref(s), width, height, sf, acc.ctypes.data, img.ctypes.data, rays, threads)
+        assert rc == 0
+    return acc, img, {"rays_total": int(rays[0]), "rays_occlusion": int(rays[1])}

@@ -22,6 +22,7 @@
 extern "C" {
 
 uint32_t ref_tea16(uint32_t a, uint32_t b) { return tea<16>(a, b); }
+uint32_t ref_tea4(uint32_t a, uint32_t b) { return tea<4>(a, b); }   // whitted.cu:196
 
 uint32_t ref_lcg(uint32_t* s)
 {

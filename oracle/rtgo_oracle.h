@@ -137,6 +137,25 @@ int oracle_render(const oracle_scene* sc, const oracle_frame* fr, float* accum, 
 /* number of local rows a (window h, band_h, n_ranks, rank) owns */
 uint32_t oracle_local_rows(uint32_t h, uint32_t band_h, uint32_t n_ranks, uint32_t rank);
 
+/* ---- the "whitted" triangle path (rtgo_oracle_whitted.c): cuda/whitted.cu + cuda/LocalGeometry.h, no textures ---- */
+typedef struct { float base_color[4]; float metallic, roughness; } oracle_pbr;                               /* MaterialData::Pbr */
+typedef struct { float color[3]; float intensity; float position[3]; int32_t falloff; } oracle_point_light;   /* Light::Point */
+typedef struct {
+    const float* positions;          /* 3 per vertex */
+    const float* normals;            /* 3 per vertex or NULL */
+    const uint32_t* indices;         /* 3 per triangle */
+    const uint32_t* tri_material;    /* per triangle or NULL */
+    const oracle_pbr* materials;
+    const oracle_point_light* lights;
+    uint32_t n_vertices, n_triangles, n_materials, n_lights;
+    float eye[3], U[3], V[3], W[3], miss[3];
+} oracle_whitted_scene;
+uint32_t oracle_tea4(uint32_t v0, uint32_t v1);                                                               /* random.h:30-45, N = 4 */
+int oracle_tri_intersect(const float* p0, const float* p1, const float* p2, const float* o, const float* d, float tmin, float tmax,
+                         float* t, float* u, float* v);
+int oracle_whitted_render(const oracle_whitted_scene* s, uint32_t width, uint32_t height, uint32_t subframe, float* accum, uint8_t* image,
+                          uint64_t* rays, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@ SYMBOLS = [
     "rtgo_set_background", "rtgo_set_lights", "rtgo_resize", "rtgo_bind_output", "rtgo_launch", "rtgo_sync",
     "rtgo_read_image", "rtgo_read_accum", "rtgo_write_accum", "rtgo_get_stats", "rtgo_reset_stats", "rtgo_read_bvh",
     "rtgo_local_rows", "rtgo_abi_version", "rtgo_assemble_bands",
+    "rtgo_whitted_set_mesh", "rtgo_whitted_set_lights", "rtgo_whitted_set_miss_color", "rtgo_whitted_launch",
 ]
 
 
@@ -100,6 +101,10 @@ def load():
     L.rtgo_local_rows.restype = C.c_uint32
     L.rtgo_local_rows.argtypes = [C.c_uint32] * 4
     L.rtgo_assemble_bands.argtypes = [vp, vp, vp, vp] + [C.c_uint32] * 6
+    L.rtgo_whitted_set_mesh.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_uint32]
+    L.rtgo_whitted_set_lights.argtypes = [vp, vp, C.c_uint32]
+    L.rtgo_whitted_set_miss_color.argtypes = [vp, fp]
+    L.rtgo_whitted_launch.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("rtgo_last_error", "rtgo_local_rows", "rtgo_abi_version"):
@@ -218,6 +223,28 @@ class Context:
     def write_accum(self, accum):
         a = np.ascontiguousarray(accum, dtype=np.float32)
         self._check(self._lib.rtgo_write_accum(self._h, a.ctypes.data, a.nbytes), "rtgo_write_accum")
+
+    # ---- the whitted triangle path (cuda/whitted.cu), one call per C-ABI entry ----
+    def whitted_set_mesh(self, positions, normals, indices, tri_material, materials):
+        pos = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        nrm = None if normals is None else np.ascontiguousarray(normals, dtype=np.float32).reshape(-1, 3)
+        idx = np.ascontiguousarray(indices, dtype=np.uint32).reshape(-1, 3)
+        tm = None if tri_material is None else np.ascontiguousarray(tri_material, dtype=np.uint32)
+        mats = np.ascontiguousarray(materials, dtype=np.float32).reshape(-1, 6)
+        self._check(self._lib.rtgo_whitted_set_mesh(self._h, pos.ctypes.data, nrm.ctypes.data if nrm is not None else None, len(pos),
+                                                    idx.ctypes.data, tm.ctypes.data if tm is not None else None, len(idx),
+                                                    mats.ctypes.data, len(mats)), "rtgo_whitted_set_mesh")
+
+    def whitted_set_lights(self, lights8):
+        l = np.ascontiguousarray(lights8, dtype=np.float32).reshape(-1, 8)
+        self._check(self._lib.rtgo_whitted_set_lights(self._h, l.ctypes.data if len(l) else None, len(l)), "rtgo_whitted_set_lights")
+
+    def whitted_set_miss_color(self, rgb):
+        a, p = _f3(rgb)
+        self._check(self._lib.rtgo_whitted_set_miss_color(self._h, p), "rtgo_whitted_set_miss_color")
+
+    def whitted_launch(self, width, height, subframe):
+        self._check(self._lib.rtgo_whitted_launch(self._h, width, height, subframe), "rtgo_whitted_launch")
 
     def stats(self):
         s = Stats()

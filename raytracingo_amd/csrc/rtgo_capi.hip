@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file: every path ends in a HIP launch or an error code.
 #include "../../include/rtgo.h"
 #include "rtgo_device.h"
+#include "rtgo_whitted.h"
 
 #include <cmath>
 #include <cstdio>
@@ -68,8 +69,23 @@ struct rtgo_ctx {
 #endif
     float total_ms = 0.0f, last_ms = 0.0f;
     uint32_t launches = 0;
+    // the whitted triangle path (rtgo_whitted.h)
+    float* w_positions = nullptr;
+    float* w_normals = nullptr;
+    unsigned int* w_indices = nullptr;
+    unsigned int* w_tri_material = nullptr;
+    whitted::Pbr* w_materials = nullptr;
+    whitted::PointLight* w_lights = nullptr;
+    float4* w_nodes = nullptr;
+    int* w_scratch = nullptr;
+    int w_triangles = 0, w_n_lights = 0, w_n_materials = 0;
+    v3 w_miss{0, 0, 0};
     std::string err;
 };
+
+static_assert(sizeof(rtgo_pbr) == sizeof(whitted::Pbr) && sizeof(rtgo_point_light) == sizeof(whitted::PointLight) && sizeof(rtgo_point_light) == 32,
+              "whitted records");
+static_assert(RTGO_MAX_TRIANGLES == whitted::kMaxTriangles, "limits");
 
 static std::string g_create_error;
 
@@ -292,6 +308,14 @@ int rtgo_destroy(rtgo_ctx* c)
     }
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->w_positions);
+    (void)hipFree(c->w_normals);
+    (void)hipFree(c->w_indices);
+    (void)hipFree(c->w_tri_material);
+    (void)hipFree(c->w_materials);
+    (void)hipFree(c->w_lights);
+    (void)hipFree(c->w_nodes);
+    (void)hipFree(c->w_scratch);
     for (int i = 0; i < rtgo_ctx::kEvRing; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -672,6 +696,135 @@ int rtgo_assemble_bands(rtgo_ctx* c, void* hip_stream, const void* d_gathered, v
         hipLaunchKernelGGL(assemble_bands_kernel<unsigned int>, dim3((unsigned int)blocks), dim3(256), 0, st, (const unsigned int*)d_gathered,
                            (unsigned int*)d_full, (unsigned int)(row_bytes / 4), h, band_h, n_ranks, rows_pad);
     RTGO_HIP(c, hipGetLastError());
+    return RTGO_OK;
+}
+
+int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* normals, uint32_t n_vertices, const uint32_t* indices,
+                          const uint32_t* material_of_triangle, uint32_t n_triangles, const rtgo_pbr* materials, uint32_t n_materials)
+{
+    if (!c || !positions || !indices || !materials) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_mesh: NULL argument");
+    if (n_triangles == 0 || n_triangles > RTGO_MAX_TRIANGLES || n_vertices == 0 || n_materials == 0)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_mesh: triangle count must be in [1, " + std::to_string(RTGO_MAX_TRIANGLES) + "], vertices and materials non-empty");
+    for (uint32_t i = 0; i < 3 * n_triangles; ++i)
+        if (indices[i] >= n_vertices) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_mesh: index beyond the vertex array");
+    for (uint32_t i = 0; i < 3 * n_vertices; ++i)
+        if (!std::isfinite(positions[i]) || (normals && !std::isfinite(normals[i]))) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_mesh: non-finite vertex data");
+    if (material_of_triangle)
+        for (uint32_t i = 0; i < n_triangles; ++i)
+            if (material_of_triangle[i] >= n_materials) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_mesh: material index beyond the material array");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->w_positions);
+    (void)hipFree(c->w_normals);
+    (void)hipFree(c->w_indices);
+    (void)hipFree(c->w_tri_material);
+    (void)hipFree(c->w_materials);
+    (void)hipFree(c->w_nodes);
+    (void)hipFree(c->w_scratch);
+    c->w_positions = c->w_normals = nullptr;
+    c->w_indices = c->w_tri_material = nullptr;
+    c->w_materials = nullptr;
+    c->w_nodes = nullptr;
+    c->w_scratch = nullptr;
+    c->w_triangles = 0;
+    const size_t vb = (size_t)n_vertices * 3 * sizeof(float), ib = (size_t)n_triangles * 3 * sizeof(unsigned int);
+    RTGO_HIP(c, hipMalloc(&c->w_positions, vb));
+    RTGO_HIP(c, hipMemcpyAsync(c->w_positions, positions, vb, hipMemcpyHostToDevice, c->stream));
+    if (normals) {
+        RTGO_HIP(c, hipMalloc(&c->w_normals, vb));
+        RTGO_HIP(c, hipMemcpyAsync(c->w_normals, normals, vb, hipMemcpyHostToDevice, c->stream));
+    }
+    RTGO_HIP(c, hipMalloc(&c->w_indices, ib));
+    RTGO_HIP(c, hipMemcpyAsync(c->w_indices, indices, ib, hipMemcpyHostToDevice, c->stream));
+    if (material_of_triangle) {
+        RTGO_HIP(c, hipMalloc(&c->w_tri_material, (size_t)n_triangles * sizeof(unsigned int)));
+        RTGO_HIP(c, hipMemcpyAsync(c->w_tri_material, material_of_triangle, (size_t)n_triangles * sizeof(unsigned int), hipMemcpyHostToDevice, c->stream));
+    }
+    RTGO_HIP(c, hipMalloc(&c->w_materials, (size_t)n_materials * sizeof(whitted::Pbr)));
+    RTGO_HIP(c, hipMemcpyAsync(c->w_materials, materials, (size_t)n_materials * sizeof(whitted::Pbr), hipMemcpyHostToDevice, c->stream));
+    RTGO_HIP(c, hipMalloc(&c->w_nodes, (size_t)(2 * n_triangles - 1) * 2 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(3 * n_triangles + 8) * sizeof(int)));   // parent [2n-1], visit [n], meta
+    int* parent = c->w_scratch;
+    int* visit = parent + (2 * n_triangles - 1);
+    int* meta = visit + n_triangles;
+    hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), 0, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
+                       parent, visit, meta);
+    RTGO_HIP(c, hipGetLastError());
+    int depth = 0;
+    RTGO_HIP(c, hipMemcpyAsync(&depth, meta, sizeof depth, hipMemcpyDeviceToHost, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    if (depth > whitted::kStack)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_mesh: triangle LBVH depth " + std::to_string(depth) + " exceeds the traversal stack (" +
+                                               std::to_string(whitted::kStack) + ")");
+    c->w_triangles = (int)n_triangles;
+    c->w_n_materials = (int)n_materials;
+    return RTGO_OK;
+}
+
+int rtgo_whitted_set_lights(rtgo_ctx* c, const rtgo_point_light* lights, uint32_t n)
+{
+    if (!c || (n > 0 && !lights)) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_lights: bad argument");
+    if (n > RTGO_MAX_LIGHTS) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_lights: at most " + std::to_string(RTGO_MAX_LIGHTS) + " lights");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    if (!c->w_lights) RTGO_HIP(c, hipMalloc(&c->w_lights, RTGO_MAX_LIGHTS * sizeof(whitted::PointLight)));
+    if (n > 0) RTGO_HIP(c, hipMemcpyAsync(c->w_lights, lights, n * sizeof(whitted::PointLight), hipMemcpyHostToDevice, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    c->w_n_lights = (int)n;
+    return RTGO_OK;
+}
+
+int rtgo_whitted_set_miss_color(rtgo_ctx* c, const float rgb[3])
+{
+    if (!c || !rgb) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_miss_color: NULL argument");
+    c->w_miss = v3{rgb[0], rgb[1], rgb[2]};
+    return RTGO_OK;
+}
+
+int rtgo_whitted_launch(rtgo_ctx* c, uint32_t width, uint32_t height, uint32_t subframe_index)
+{
+    if (!c) return RTGO_E_INVALID;
+    if (c->w_triangles == 0) return fail(c, RTGO_E_STATE, "rtgo_whitted_launch: no mesh (call rtgo_whitted_set_mesh)");
+    if (!c->have_camera) return fail(c, RTGO_E_STATE, "rtgo_whitted_launch: no camera (call rtgo_set_camera)");
+    if (!c->d_accum || !c->d_image) return fail(c, RTGO_E_STATE, "rtgo_whitted_launch: no output (call rtgo_resize or rtgo_bind_output)");
+    if (width == 0 || height == 0 || (uint64_t)width * height > c->pixels) return fail(c, RTGO_E_INVALID, "rtgo_whitted_launch: image empty or larger than the output buffers");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    if (!c->w_lights) RTGO_HIP(c, hipMalloc(&c->w_lights, RTGO_MAX_LIGHTS * sizeof(whitted::PointLight)));
+    whitted::Params p;
+    std::memset(&p, 0, sizeof p);
+    p.nodes = c->w_nodes;
+    p.positions = c->w_positions;
+    p.normals = c->w_normals;
+    p.indices = c->w_indices;
+    p.tri_material = c->w_tri_material;
+    p.materials = c->w_materials;
+    p.lights = c->w_lights;
+    p.n_triangles = c->w_triangles;
+    p.n_lights = c->w_n_lights;
+    p.accum = c->d_accum;
+    p.image = c->d_image;
+    p.width = width;
+    p.height = height;
+    p.subframe = subframe_index;
+    p.eye = c->eye;
+    p.U = c->U;
+    p.V = c->V;
+    p.W = c->W;
+    p.miss = c->w_miss;
+    p.counters = c->d_counters;
+    if (c->ev_pending == rtgo_ctx::kEvRing) {
+        int rc = harvest_events(c, 1);
+        if (rc) return rc;
+    }
+    const int slot = c->ev_head;
+    RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
+    const unsigned int blocks = (unsigned int)(((uint64_t)width * height + whitted::kBlock - 1) / whitted::kBlock);
+    hipLaunchKernelGGL(whitted::render_kernel, dim3(blocks), dim3(whitted::kBlock), 0, c->stream, p);
+    RTGO_HIP(c, hipGetLastError());
+    RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
+    c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;
+    c->ev_pending++;
+    c->launches++;
     return RTGO_OK;
 }
 

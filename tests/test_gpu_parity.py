@@ -838,3 +838,97 @@ def test_assemble_bands_odd_shapes(capi):
         assert np.array_equal(d_f.cpu().numpy(), full), (w, h, band_h, G, elem)
     assert L.rtgo_assemble_bands(ctx._h, None, d_g.data_ptr(), d_f.data_ptr(), 21, 40, 3, 4, 2, 16) != 0   # rows_pad too small
     ctx.close()
+
+
+# ---- the whitted triangle path (cuda/whitted.cu): SURVEY 8f row f4 --------------------------------------------------------------
+def _whitted_ctx(capi, mesh, cam, W, H):
+    ctx = capi.Context(0)
+    ctx.whitted_set_mesh(mesh["positions"], mesh.get("normals"), mesh["indices"], mesh.get("tri_material"), mesh["materials"])
+    ctx.whitted_set_lights(mesh["lights"])
+    ctx.whitted_set_miss_color(mesh["miss"])
+    ctx.set_camera(cam[0:3], cam[3:6], cam[6:9], cam[9:12])
+    ctx.resize(W * H)
+    return ctx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["smooth", "faceted", "one_light_fine"])
+def test_whitted_triangles_against_the_oracle(capi, oracle, variant):
+    """__raygen__pinhole / __closesthit__radiance / __closesthit__occlusion / __miss__constant_radiance of cuda/whitted.cu over a
+    procedural triangle scene (tests/whitted_scene.py), subframes 0..3 accumulated (whitted.cu:226-239), against the oracle's
+    brute-force restatement.  The device walks an LBVH it built itself; the triangle test and the closest-hit rule are shared
+    operation for operation, so which triangle a ray hits, and where, agree exactly -- what differs is the device libm
+    (powf in schlick and make_color, sqrtf): tolerance 1e-4 relative on the float buffer, 1 LSB on the 8-bit image."""
+    import whitted_scene
+    W, H = 160, 100
+    mesh = whitted_scene.build(n_lat=40, n_lon=48) if variant == "one_light_fine" else whitted_scene.build()
+    if variant == "faceted":
+        mesh = dict(mesh, normals=None)
+    if variant == "one_light_fine":
+        mesh = dict(mesh, lights=mesh["lights"][:1])          # ~3.8 k triangles: close to RTGO_MAX_TRIANGLES
+        assert 3000 < len(mesh["indices"]) <= 4096
+    cam = whitted_scene.camera(oracle, W, H)
+    ctx = _whitted_ctx(capi, mesh, cam, W, H)
+    ctx.reset_stats()
+    for sf in range(4):
+        ctx.whitted_launch(W, H, sf)
+    ctx.sync()
+    acc, img = ctx.read_accum(H, W), ctx.read_image(H, W)
+    st = ctx.stats()
+    racc, rimg, rc = oracle.whitted_render(mesh, cam, W, H, 4)
+    m = assert_parity(acc, racc, img, rimg, what="whitted " + variant)
+    assert abs(st["rays_total"] - rc["rays_total"]) <= 0.002 * rc["rays_total"]
+    assert abs(st["rays_occlusion"] - rc["rays_occlusion"]) <= 0.002 * rc["rays_occlusion"]
+    # subframe 0 alone: no jitter, so primary hits are identical and the ray counts must agree exactly
+    ctx.reset_stats()
+    ctx.whitted_launch(W, H, 0)
+    ctx.sync()
+    r0, _, c0 = oracle.whitted_render(mesh, cam, W, H, 1)
+    st0 = ctx.stats()
+    assert st0["rays_total"] == c0["rays_total"] and st0["rays_occlusion"] == c0["rays_occlusion"]
+    a0 = ctx.read_accum(H, W)
+    assert np.array_equal(a0[..., 3], r0[..., 3])
+    # pixels that see only the miss colour are exact
+    miss_px = (r0[..., :3] == mesh["miss"]).all(axis=-1)
+    assert miss_px.any() and np.array_equal(a0[miss_px], r0[miss_px])
+    print("whitted", variant, m, st0["last_launch_ms"], "ms,", len(mesh["indices"]), "triangles")
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_whitted_edge_cases(capi, oracle):
+    """one triangle (the tree is a single leaf), a camera inside the mesh's box, no lights, and the argument checks"""
+    import whitted_scene
+    W, H = 64, 48
+    one = {"positions": np.array([[-1, 0, 0], [1, 0, 0], [0, 1.5, 0]], np.float32), "normals": None, "indices": np.array([[0, 1, 2]], np.uint32),
+           "tri_material": None, "materials": np.array([[0.7, 0.7, 0.7, 1, 0.0, 0.5]], np.float32),
+           "lights": np.array([[1, 1, 1, 3.0, 0.5, 1.0, 3.0, 0]], np.float32), "miss": np.array([0.0, 0.1, 0.0], np.float32)}
+    cam = whitted_scene.camera(oracle, W, H, eye=(0.2, 0.6, 4.0), lookat=(0, 0.6, 0))
+    ctx = _whitted_ctx(capi, one, cam, W, H)
+    ctx.whitted_launch(W, H, 0)
+    ctx.sync()
+    racc, rimg, _ = oracle.whitted_render(one, cam, W, H, 1)
+    assert_parity(ctx.read_accum(H, W), racc, ctx.read_image(H, W), rimg, what="one triangle")
+    ctx.close()
+    mesh = whitted_scene.build()
+    cam = whitted_scene.camera(oracle, W, H, eye=(-1.2, 1.2, 0.3), lookat=(2.0, 1.0, 0.3))     # inside the sphere
+    for lights in (mesh["lights"], np.zeros((0, 8), np.float32)):
+        m2 = dict(mesh, lights=lights)
+        ctx = _whitted_ctx(capi, m2, cam, W, H)
+        ctx.whitted_launch(W, H, 0)
+        ctx.whitted_launch(W, H, 1)
+        ctx.sync()
+        racc, rimg, _ = oracle.whitted_render(m2, cam, W, H, 2)
+        assert_parity(ctx.read_accum(H, W), racc, ctx.read_image(H, W), rimg, what="camera inside, %d lights" % len(lights))
+        ctx.close()
+    ctx = capi.Context(0)
+    with pytest.raises(capi.RtgoError):
+        ctx.whitted_launch(W, H, 0)                                          # no mesh
+    with pytest.raises(capi.RtgoError):
+        ctx.whitted_set_mesh(one["positions"], None, np.array([[0, 1, 3]], np.uint32), None, one["materials"])    # index beyond the vertices
+    big = np.zeros((4097, 3), np.uint32)
+    with pytest.raises(capi.RtgoError):
+        ctx.whitted_set_mesh(one["positions"], None, big, None, one["materials"])                                # too many triangles
+    with pytest.raises(capi.RtgoError):
+        ctx.whitted_set_mesh(one["positions"], None, one["indices"], np.array([1], np.uint32), one["materials"])  # material beyond the table
+    ctx.close()
