@@ -546,6 +546,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         uint32_t grab = (uint32_t)(units_hot / (waves_guess * 32u));
         const uint32_t grab_cap = env_uint("RTGO_GRAB_MAX", (uint32_t)kUnitsPerGrab);
         const uint32_t grab_max = (64u / unit_px) < grab_cap ? (64u / unit_px) : grab_cap;
+        const uint32_t grab_min = env_uint("RTGO_GRAB_MIN", 1u);   // (experiment knob)
+        grab = grab < grab_min ? grab_min : grab;
         grab = grab < 1u ? 1u : (grab > grab_max ? grab_max : grab);
         p.grab = grab;
     }
