@@ -23,13 +23,13 @@ LDS_PEAK_GBS = 150000.0  # ds_read_b64/b128 with every CU streaming at ~2.4 GHz,
 
 
 def committed_profile(scene, W, H, mode, N):
-    """The newest committed PMC profile of this workload (profiles/*/summary.json, written by tools/profile_round.sh from separate
+    """The latest committed PMC profile of this workload (profiles/*/summary.json, written by tools/profile_round.sh from separate
     rocprofv3 --pmc passes): HBM bytes per launch, and what binds the kernel -- vector issue slots filled, lanes live in them,
     vector / scalar instructions per traversed ray.  None when there is none."""
     import glob
     best = None
     key = "%s %dx%d --mode=%s --sample=%d" % (scene, W, H, mode, N)
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json")), key=os.path.getmtime):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):   # (by name: rNNx tags sort by round)
         try:
             j = json.load(open(f))
             if key in j["bench"]["config"]["workload"] and "hbm_traffic_bytes_per_launch" in j:
