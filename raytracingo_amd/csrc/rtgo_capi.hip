@@ -42,6 +42,7 @@ struct rtgo_ctx {
     int lbvh_depth = 0;
     int fast_depth = 0;
     int n_small = 0;
+    int n_fnodes = 0;             // nodes of the fast walk's tree
     int n_big_pairs = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};  // tight world bounds of the scene (min xyz, max xyz)
     int leaf_budget = kDefaultLeafBudget;
@@ -88,6 +89,9 @@ static_assert(sizeof(rtgo_pbr) == sizeof(whitted::Pbr) && sizeof(rtgo_point_ligh
 static_assert(RTGO_MAX_TRIANGLES == whitted::kMaxTriangles, "limits");
 
 static std::string g_create_error;
+
+// dynamic LDS of build_kernel: the fast walk's tree while it is built and rotated (2 * kMaxPrims nodes x (box 24 B + two links + parent))
+static constexpr size_t kBuildDynLds = (size_t)2 * kMaxPrims * (6 * sizeof(float) + 3 * sizeof(int));
 
 // every instantiation of the megakernel, in one place: rtgo_create raises the dynamic-LDS limit of each, rtgo_launch picks one
 using RenderKernel = void (*)(const LaunchParams, const float4*);
@@ -278,6 +282,8 @@ int rtgo_create(int device, rtgo_ctx** out)
     const int max_lds = 160 * 1024;
     for (const RenderKernelEntry& e : kRenderKernels)
         if (err == hipSuccess) err = hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+    // (the build kernel holds ~58 KB of static LDS; its dynamic part is the fast walk's tree under construction)
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildDynLds);
     if (err == hipSuccess) err = hipDeviceSynchronize();  // the null-stream memsets above must land before any launch
     if (err != hipSuccess) {
         std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
@@ -386,11 +392,11 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     }
     RTGO_HIP(c, hipMemcpyAsync(c->d_prims_in, prims, n * sizeof(PrimIn), hipMemcpyHostToDevice, c->stream));
     if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), 0, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
+    hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), kBuildDynLds, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
                        (float)env_uint("RTGO_BIG_PERCENT", 40) * 0.01f, c->d_meta);
     RTGO_HIP(c, hipGetLastError());
-    int meta[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int meta[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     const int depth = meta[0];
@@ -398,6 +404,9 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     c->fast_depth = meta[1];
     c->n_small = meta[2];
     c->n_big_pairs = meta[9];
+    c->n_fnodes = meta[10];
+    if (c->n_fnodes < 0 || c->n_fnodes > 2 * (int)n - 1 || (c->n_small > 0 && c->n_fnodes < 1))
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: the fast walk's tree has " + std::to_string(c->n_fnodes) + " nodes");
     std::memcpy(c->bounds, &meta[3], sizeof c->bounds);
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
@@ -576,6 +585,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
     p.fnodes = c->d_fnodes;
+    p.n_fnodes = c->n_fnodes;
     p.fprims = c->d_fprims;
     p.n_small = c->n_small;
     p.n_big_pairs = c->n_big_pairs;
@@ -610,7 +620,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
     // The scene copy is per workgroup and the stack per lane, so bigger scenes want bigger workgroups: pick the size that
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
-    const int fast_nodes = c->n_small > 0 ? 2 * c->n_small - 1 : 0;
+    const int fast_nodes = c->n_fnodes;
     const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims) * sizeof(float4) +
                              (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float);   // + the raygen constants
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;

@@ -42,7 +42,8 @@ struct LightRec {
 struct LaunchParams {
     const float4* nodes;            // canonical LBVH, 2 float4 per node
     const float4* prims;            // 6 float4 per primitive, SBT order
-    const float4* fnodes;           // collapsed LBVH for the fast walk: same indexing, subtrees whose leaf cost fits the budget are leaves
+    const float4* fnodes;           // the fast walk's tree: 2 float4 per node, root 0; leaf: left = first record, right = -(count | pairs << 12)
+    int n_fnodes;
     const float4* fprims;           // 4 float4 per primitive in Morton order: rows 0..2 of M^-1, (bits(type), bits(SBT index), 0, 0)
     int stack_depth;                // per-lane LDS stack entries this launch needs
     int n_small;                    // fast walk: fprims [0, n_small) are in the tree, [n_small, n_prims) are tested up front
@@ -792,7 +793,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
     //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][stack, 4 B/entry][lights]
     constexpr int MS = STATS ? 6 : 3;  // float4 stride between two primitives' material rows (kd|spec, kr|type, Le)
-    const int n_nodes = STATS ? p.n_nodes : (p.n_small > 0 ? 2 * p.n_small - 1 : 0);
+    const int n_nodes = STATS ? p.n_nodes : p.n_fnodes;
     float4* s_nodes = reinterpret_cast<float4*>(smem);
     float4* s_prims = s_nodes + 2 * n_nodes;
     float4* s_mat_w = STATS ? s_prims + 3 : s_prims + 4 * p.n_prims;
@@ -1358,7 +1359,8 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
 // Outputs.  out_nodes: (2n-1) x 2 float4 canonical LBVH; out_prims: n x 6 float4 (SBT order); aabb_io: n x 6 floats (read when
 // have_aabb, else written); out_fnodes / out_fprims: the fast walk's tree (2*n_small-1 nodes) and Morton-ordered records
 // (small primitives first, then the "big" ones that are tested up front);
-// out_meta = {canonical depth, fast-walk stack depth, n_small, tight scene bounds (6 floats as bits)}.
+// out_meta = {canonical depth, fast-walk stack depth, n_small, tight scene bounds (6 floats as bits), pairs in the up-front list,
+// nodes of the fast walk's tree}.
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
@@ -1398,9 +1400,11 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         }
     };
     // 30-bit Morton code of primitive i's box centre normalised to the bounds in s_red[..][0]
-    auto morton_of = [&](int first = -1, int count = 1) -> unsigned int {   // centre of the union of the boxes [first, first + count)
+    auto morton_of = [&](int first = -1, int count = 1, bool cubic = false) -> unsigned int {   // centre of the union of the boxes [first, first + count)
         if (first < 0) first = i;
         unsigned int q[3];
+        // cubic: one scale for the three axes (the longest extent), so that a Morton cell is a cube and not a slab
+        const float emax = fmaxf(fmaxf(s_red[3][0] - s_red[0][0], s_red[4][0] - s_red[1][0]), s_red[5][0] - s_red[2][0]);
         for (int a = 0; a < 3; ++a) {
             float lo = s_box[first][a], hi = s_box[first][3 + a];
             for (int k = 1; k < count; ++k) {
@@ -1408,7 +1412,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
                 hi = fmaxf(hi, s_box[first + k][3 + a]);
             }
             const float c = (lo + hi) * 0.5f;
-            const float ext = s_red[3 + a][0] - s_red[a][0];
+            const float ext = cubic ? emax : s_red[3 + a][0] - s_red[a][0];
             const float u = ext > 0.0f ? (c - s_red[a][0]) / ext : 0.0f;
             q[a] = (unsigned int)fminf(fmaxf(u * 1024.0f, 0.0f), 1023.0f);
         }
@@ -1626,7 +1630,8 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     // small primitives sort by Morton code; big ones after them, in SBT order
     {
         const bool boxed = i < n && s_used[i] != 0xFF;
-        const unsigned int code = (i < n && !big) ? (boxed ? morton_of(i - (int)s_used[i], 6) : morton_of()) : 0u;
+        const bool cubic = true;   // (balls -1 %, plateau -1 %, slide -2.5 % against per-axis scaling; nothing lost elsewhere)
+        const unsigned int code = (i < n && !big) ? (boxed ? morton_of(i - (int)s_used[i], 6, cubic) : morton_of(-1, 1, cubic)) : 0u;
         s_keys[i] = (i < n) ? ((big ? (0xFFFFFFFEull << 32) : ((unsigned long long)code << 32)) | (unsigned int)i) : ~0ull;
     }
     sort_keys();
@@ -1732,26 +1737,236 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
             out_fprims[4 * i + 2] = out_prims[6 * prim + 2];
             out_fprims[4 * i + 3] = make_float4(__int_as_float((int)prims[prim].type), __int_as_float(prim), 0.0f, 0.0f);
         }
-        for (int k = i; k < 2 * n_small - 1; k += kMaxPrims) {
-            int fl, fr;  // collapsed leaf = (first Morton position, -count)
-            if (k >= leaf0) {
-                fl = k - leaf0;
-                fr = -1;
-            } else if (s_wt[k] <= leaf_budget) {
-                fl = s_lo[k];
-                fr = -(((int)s_hi[k] - (int)s_lo[k] + 1) | (s_visit[k] << 12));   // count | pairs << 12
-            } else {
-                fl = s_left[k];
-                fr = s_right[k];
+        // ---- the tree the walk uses: a top-down surface-area-heuristic build over the walk's UNITS.  A unit is a maximal collapsed
+        // subtree of the Morton hierarchy above (cost <= budget: one multi-record leaf whose records are contiguous) or a single
+        // primitive; the hierarchy only serves to form them.  Above the units the Morton prefixes are a poor guide for rays (they
+        // know nothing of box areas), and any tree over the same leaves returns the same closest hit, so the topology is rebuilt:
+        // every node is split where A(left) * W(left) + A(right) * W(right) is smallest over the three axes and every position of
+        // the units sorted by centroid (W = leaf-test cost weights).  All 512 threads walk one task queue together: a rank sort per
+        // axis in parallel, the sweep by one thread.  (Rotations of the Morton tree gave balls -4.5 %; this build ... see DESIGN.)
+        short* s_unit = reinterpret_cast<short*>(s_keys);    // (the sort keys are no longer needed) [kMaxPrims] binary node of unit u
+        short* s_perm = s_unit + kMaxPrims;                  // [kMaxPrims] the units in the current task order
+        short* s_tmp = s_perm + kMaxPrims;                   // [kMaxPrims]
+        float* s_sfx = &s_box[0][0];                         // (the primitive boxes are no longer needed) [kMaxPrims][7]: suffix box + weight
+        short* s_tq_node = reinterpret_cast<short*>(s_parent);   // task queue, <= 2 * units - 1 entries: node, lo, hi, depth
+        short* s_tq_lo = s_tq_node + 2 * kMaxPrims;
+        short* s_tq_hi = reinterpret_cast<short*>(s_wt);         // (s_wt is read until the units are formed; see the barrier below)
+        short* s_tq_dep = s_tq_hi + 2 * kMaxPrims;
+        __shared__ int s_qtail, s_best_axis, s_best_pos, s_units;
+        // the tree under construction (dynamic LDS, 2 * kMaxPrims nodes): box, links, parent -- rotated below, then written out
+        extern __shared__ __attribute__((aligned(16))) unsigned char build_dyn[];
+        float (*t_box)[6] = reinterpret_cast<float (*)[6]>(build_dyn);
+        int* t_left = reinterpret_cast<int*>(t_box + 2 * kMaxPrims);
+        int* t_right = t_left + 2 * kMaxPrims;
+        int* t_parent = t_right + 2 * kMaxPrims;
+        auto leafish = [&](int k) { return k >= leaf0 || s_wt[k] <= leaf_budget; };
+        __syncthreads();
+        if (i < n_small) s_left[i] = -1;   // (the binary links are no longer needed) unit that starts at Morton position i
+        __syncthreads();
+        for (int k = i; k < 2 * n_small - 1; k += kMaxPrims)
+            if (leafish(k) && (s_parent[k] < 0 || s_wt[s_parent[k]] > leaf_budget)) s_left[k >= leaf0 ? k - leaf0 : s_lo[k]] = k;
+        __syncthreads();
+        if (i == 0) {
+            int L = 0;
+            for (int pos = 0; pos < n_small; ++pos)
+                if (s_left[pos] >= 0) s_unit[L++] = (short)s_left[pos];
+            s_units = L;
+        }
+        __syncthreads();
+        const int L = s_units;
+        // per unit: weight (kept in s_right, an int array that is free now) -- after this barrier s_wt and s_parent are reused
+        if (i < L) {
+            const int k = s_unit[i];
+            s_right[i] = s_wt[k] < 1 ? 1 : s_wt[k];
+            s_perm[i] = (short)i;
+        }
+        __syncthreads();
+        if (i == 0) {
+            s_tq_node[0] = 0;
+            s_tq_lo[0] = 0;
+            s_tq_hi[0] = (short)L;
+            s_tq_dep[0] = 0;
+            s_qtail = L > 0 ? 1 : 0;
+            s_count = L > 0 ? 1 : 0;   // nodes allocated
+            s_depth = 0;
+            t_parent[0] = -1;
+        }
+        __syncthreads();
+        auto ubox = [&](int u, int c) { return s_nbox[s_unit[u]][c]; };
+        for (int qi = 0; qi < 2 * kMaxPrims; ++qi) {
+            __syncthreads();
+            if (qi >= s_qtail) break;   // (uniform: every thread reads the same word after the barrier)
+            const int lo = s_tq_lo[qi], hi = s_tq_hi[qi], node = s_tq_node[qi], dep = s_tq_dep[qi], m = hi - lo;
+            if (m == 1) {
+                if (i == 0) {
+                    const int k = s_unit[s_perm[lo]];
+                    const int first = k >= leaf0 ? k - leaf0 : (int)s_lo[k];
+                    const int cnt = k >= leaf0 ? 1 : (int)s_hi[k] - (int)s_lo[k] + 1;
+                    const int npairs = k >= leaf0 ? 0 : s_visit[k];
+                    for (int c = 0; c < 6; ++c) t_box[node][c] = s_nbox[k][c];
+                    t_left[node] = first;
+                    t_right[node] = -(cnt | (npairs << 12));
+                }
+                continue;
             }
-            out_fnodes[2 * k + 0] = make_float4(s_nbox[k][0], s_nbox[k][1], s_nbox[k][2], __int_as_float(fl));
-            out_fnodes[2 * k + 1] = make_float4(s_nbox[k][3], s_nbox[k][4], s_nbox[k][5], __int_as_float(fr));
+            if (i == 0) {
+                s_best_axis = -1;
+                s_best_pos = m / 2;
+            }
+            float best_cost = INFINITY;   // (thread 0's)
+            for (int pass = 0; pass < 4; ++pass) {
+                // passes 0..2: try axis `pass`; pass 3: put the range back in the order of the best axis
+                __syncthreads();
+                const int axis = pass < 3 ? pass : s_best_axis;
+                if (pass == 3 && (axis < 0 || axis == 2)) break;   // (uniform) no finite cost at all, or already in z order
+                if (i < m) {
+                    const int me = s_perm[lo + i];
+                    const float key = ubox(me, axis) + ubox(me, 3 + axis);
+                    int rank = 0;
+                    for (int j = 0; j < m; ++j) {
+                        const int other = s_perm[lo + j];
+                        const float kj = ubox(other, axis) + ubox(other, 3 + axis);
+                        rank += (kj < key || (kj == key && other < me)) ? 1 : 0;
+                    }
+                    s_tmp[lo + rank] = (short)me;
+                }
+                __syncthreads();
+                if (i < m) s_perm[lo + i] = s_tmp[lo + i];
+                __syncthreads();
+                if (pass < 3 && i == 0) {
+                    // suffix boxes and weights from the right, then the sweep from the left
+                    float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    int w = 0;
+                    for (int j = m - 1; j >= 1; --j) {
+                        const int u = s_perm[lo + j];
+                        for (int c = 0; c < 3; ++c) {
+                            b[c] = fminf(b[c], ubox(u, c));
+                            b[3 + c] = fmaxf(b[3 + c], ubox(u, 3 + c));
+                        }
+                        w += s_right[u];
+                        const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+                        s_sfx[2 * j + 0] = ex * ey + ey * ez + ez * ex;
+                        s_sfx[2 * j + 1] = (float)w;
+                    }
+                    float a[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    int wl = 0;
+                    for (int j = 1; j < m; ++j) {   // left = [0, j), right = [j, m)
+                        const int u = s_perm[lo + j - 1];
+                        for (int c = 0; c < 3; ++c) {
+                            a[c] = fminf(a[c], ubox(u, c));
+                            a[3 + c] = fmaxf(a[3 + c], ubox(u, 3 + c));
+                        }
+                        wl += s_right[u];
+                        const float ex = a[3] - a[0], ey = a[4] - a[1], ez = a[5] - a[2];
+                        const float cost = (ex * ey + ey * ez + ez * ex) * (float)wl + s_sfx[2 * j] * s_sfx[2 * j + 1];
+                        if (cost < best_cost) {
+                            best_cost = cost;
+                            s_best_axis = pass;
+                            s_best_pos = j;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (i == 0) {
+                // this node: box of its range, two children appended to the queue
+                float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                for (int j = lo; j < hi; ++j) {
+                    const int u = s_perm[j];
+                    for (int c = 0; c < 3; ++c) {
+                        b[c] = fminf(b[c], ubox(u, c));
+                        b[3 + c] = fmaxf(b[3 + c], ubox(u, 3 + c));
+                    }
+                }
+                const int cl = s_count, cr = s_count + 1;
+                s_count += 2;
+                for (int c = 0; c < 6; ++c) t_box[node][c] = b[c];
+                t_left[node] = cl;
+                t_right[node] = cr;
+                t_parent[cl] = node;
+                t_parent[cr] = node;
+                const int mid = lo + s_best_pos;
+                const int t = s_qtail;
+                s_tq_node[t] = (short)cl; s_tq_lo[t] = (short)lo;  s_tq_hi[t] = (short)mid; s_tq_dep[t] = (short)(dep + 1);
+                s_tq_node[t + 1] = (short)cr; s_tq_lo[t + 1] = (short)mid; s_tq_hi[t + 1] = (short)hi; s_tq_dep[t + 1] = (short)(dep + 1);
+                s_qtail = t + 2;
+            }
+        }
+        // Tree rotations (Kensler 2008) as a second pass: the top-down build is greedy, and a node may still gain from trading one
+        // child for a grandchild on the other side when that shrinks the grandchild's parent.  One thread; a handful of sweeps.
+        __syncthreads();
+        const int n_nodes = s_count;
+        if (i == 0 && n_nodes > 3) {
+            auto internal = [&](int k) { return t_right[k] >= 0; };
+            auto area2 = [&](int a, int b) {
+                float e[3];
+                for (int ax = 0; ax < 3; ++ax) e[ax] = fmaxf(t_box[a][3 + ax], t_box[b][3 + ax]) - fminf(t_box[a][ax], t_box[b][ax]);
+                return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+            };
+            auto refit = [&](int k) {
+                const int A = t_left[k], B = t_right[k];
+                for (int ax = 0; ax < 3; ++ax) {
+                    t_box[k][ax] = fminf(t_box[A][ax], t_box[B][ax]);
+                    t_box[k][3 + ax] = fmaxf(t_box[A][3 + ax], t_box[B][3 + ax]);
+                }
+            };
+            for (int pass = 0; pass < 6; ++pass) {
+                int changed = 0;
+                for (int N = 0; N < n_nodes; ++N) {
+                    if (!internal(N)) continue;
+                    const int A = t_left[N], B = t_right[N];
+                    float best = 0.0f;
+                    int which = 0;   // 1: B <-> left(A), 2: B <-> right(A), 3: A <-> left(B), 4: A <-> right(B)
+                    if (internal(A)) {
+                        const float a0 = area2(A, A);
+                        const float g1 = a0 - area2(B, t_right[A]), g2 = a0 - area2(t_left[A], B);
+                        if (g1 > best) { best = g1; which = 1; }
+                        if (g2 > best) { best = g2; which = 2; }
+                    }
+                    if (internal(B)) {
+                        const float a0 = area2(B, B);
+                        const float g3 = a0 - area2(A, t_right[B]), g4 = a0 - area2(t_left[B], A);
+                        if (g3 > best) { best = g3; which = 3; }
+                        if (g4 > best) { best = g4; which = 4; }
+                    }
+                    if (which == 0 || !(best > 1e-6f * area2(N, N))) continue;
+                    if (which <= 2) {
+                        const int g = which == 1 ? t_left[A] : t_right[A];   // the grandchild that moves up
+                        if (which == 1) t_left[A] = B; else t_right[A] = B;
+                        t_parent[B] = A;
+                        t_right[N] = g;
+                        t_parent[g] = N;
+                        refit(A);
+                    } else {
+                        const int g = which == 3 ? t_left[B] : t_right[B];
+                        if (which == 3) t_left[B] = A; else t_right[B] = A;
+                        t_parent[A] = B;
+                        t_left[N] = g;
+                        t_parent[g] = N;
+                        refit(B);
+                    }
+                    ++changed;
+                }
+                if (!changed) break;
+            }
+            s_depth = 0;
+        }
+        __syncthreads();
+        for (int k = i; k < n_nodes; k += kMaxPrims) {
+            out_fnodes[2 * k + 0] = make_float4(t_box[k][0], t_box[k][1], t_box[k][2], __int_as_float(t_left[k]));
+            out_fnodes[2 * k + 1] = make_float4(t_box[k][3], t_box[k][4], t_box[k][5], __int_as_float(t_right[k]));
+            if (t_right[k] < 0) {   // a leaf: internal nodes above it = stack entries the walk can need on the way
+                int d = 0;
+                for (int q = t_parent[k]; q >= 0; q = t_parent[q]) ++d;
+                atomicMax(&s_depth, d);
+            }
         }
     }
     __syncthreads();
     if (i == 0) {
         out_meta[1] = s_depth;
         out_meta[2] = n_small;
+        out_meta[10] = s_count;   // nodes of the walk's tree (2 * units - 1)
     }
 }
 

@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r2
 OUT=gpurun_out/r2/ab_${1:-x}.log; : > $OUT
 for round in 1 2; do
 for lib in tools/_diag/ab_*.so; do
-  for args in "cornell 1920 1080 4 path" "cornell 1920 1080 4 distributed" "balls 1920 1080 4 path" "checkered 1920 1080 4 path" "mirror_spheres 3840 2160 8 path"; do
+  for args in "cornell 1920 1080 4 path" "balls 1920 1080 4 path" "checkered 1920 1080 4 path" "mirror_spheres 3840 2160 8 path" "plateau 3840 2160 16 path" "window 1920 1080 4 path" "slide 1920 1080 4 path"; do
     r=$(RTGO_HIP_LIB=$lib timeout -k 10 120 python tools/quick_perf.py $args 2>&1 | grep "ms/frame" | sed 's/,.*//')
     echo "$(basename $lib .so) | $r" >> $OUT
   done
