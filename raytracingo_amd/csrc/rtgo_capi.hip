@@ -394,7 +394,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), kBuildDynLds, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
-                       (float)env_uint("RTGO_BIG_PERCENT", 40) * 0.01f, c->d_meta);
+                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta);
     RTGO_HIP(c, hipGetLastError());
     int meta[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));

@@ -1554,7 +1554,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     // ================= fast walk's structure =================
     // Any conservative structure returns the same closest hit, so this one is built for speed:
     //  * TIGHT per-shape boxes for rectangles and disks (the reference's CubeBox boxes span a whole cube around a flat shape);
-    //  * "big" primitives (box spanning >= 40 % of the scene on two axes: room walls, floors) stay out of the tree and are
+    //  * "big" primitives (box spanning >= 36 % of the scene on two axes: room walls, floors) stay out of the tree and are
     //    tested first, which also gives every ray an early closest-hit bound for culling the tree;
     //  * LBVH over the rest, subtrees collapsed into multi-primitive leaves by a cost budget.
     // Spheres and cylinders keep the box the canonical walk uses (the caller's / the CubeBox one): their quadratic loses its
