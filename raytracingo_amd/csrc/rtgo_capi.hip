@@ -630,7 +630,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // slower and the launch ends one unit-duration after the queue runs dry: with few units per wave the shorter tail of fewer
     // waves wins (a 1/16 share: 0.127 / 0.137 ms at 4 / 5).  A 6-waves variant (<= 80 VGPRs) ran 1 % faster still (1.209 ms) but
     // spilled 25-32 registers to scratch -- 472 MB of HBM traffic per launch against 94 MB at 5 waves and 74.6 MB of framebuffer
-    // (profiles/r02c) -- and was dropped: the kernel should not pay HBM for registers.
+    // (profiles/r02d) -- and was dropped: the kernel should not pay HBM for registers.
     const uint64_t units_per_wave4 = units_hot * (passes_of(nn)) / ((uint64_t)c->num_cus * 16u);
     const int max_wpe_work = units_per_wave4 >= 3 ? 5 : 4;
     int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);   // (experiment knob, clamped to what exists)
