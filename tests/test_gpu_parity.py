@@ -896,6 +896,23 @@ def test_whitted_triangles_against_the_oracle(capi, oracle, variant):
 
 
 @pytest.mark.gpu
+def test_whitted_against_the_committed_fixture(capi):
+    """tests/golden/oracle_whitted.npz: the GPU against stored oracle output (no oracle run needed)"""
+    import whitted_scene
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_whitted.npz"))
+    W, H = 64, 40
+    ctx = _whitted_ctx(capi, whitted_scene.build(), z["cam"], W, H)
+    ctx.reset_stats()
+    ctx.whitted_launch(W, H, 0)
+    ctx.whitted_launch(W, H, 1)
+    ctx.sync()
+    assert_parity(ctx.read_accum(H, W), z["accum"], ctx.read_image(H, W), z["image"], what="whitted fixture")
+    st = ctx.stats()
+    assert abs(st["rays_total"] - int(z["rays"][0])) <= 0.002 * int(z["rays"][0])
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_whitted_edge_cases(capi, oracle):
     """one triangle (the tree is a single leaf), a camera inside the mesh's box, no lights, and the argument checks"""
     import whitted_scene

@@ -63,3 +63,15 @@ def test_pipeline_properties(oracle):
     flat = dict(mesh, normals=None)
     accf, _, _ = oracle.whitted_render(flat, cam, W, H, 1)
     assert not np.array_equal(accf, acc0)
+
+
+def test_committed_whitted_render_reproduces_bitwise(oracle):
+    """tests/golden/oracle_whitted.npz (oracle/gen_golden.py): the restatement is deterministic, threads or not"""
+    z = np.load(os.path.join(GOLD, "oracle_whitted.npz"))
+    W, H = 64, 40
+    mesh = whitted_scene.build()
+    cam = whitted_scene.camera(oracle, W, H)
+    assert np.array_equal(cam.view(np.uint32), z["cam"].view(np.uint32))
+    acc, img, c = oracle.whitted_render(mesh, cam, W, H, 2)
+    assert np.array_equal(acc.view(np.uint32), z["accum"].view(np.uint32)) and np.array_equal(img, z["image"])
+    assert [c["rays_total"], c["rays_occlusion"]] == z["rays"].tolist()
