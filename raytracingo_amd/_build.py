@@ -63,7 +63,8 @@ def _run_to(out, cmd_before_out, cmd_after_out, verbose):
 
 def build_hip(force=False, verbose=False):
     src = os.path.join(PKG, "csrc", "rtgo_capi.hip")
-    deps = [src, os.path.join(PKG, "csrc", "rtgo_device.h"), os.path.join(ROOT, "include", "rtgo.h")]
+    csrc = os.path.join(PKG, "csrc")
+    deps = [src, os.path.join(ROOT, "include", "rtgo.h")] + [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".inc"))]
     out = os.path.join(PKG, "librtgo_hip.so")
     if force or _stale(out, deps):
         with _build_lock():

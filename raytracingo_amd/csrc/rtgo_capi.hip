@@ -30,6 +30,19 @@ struct rtgo_ctx {
     static constexpr int kEvRing = 64;
     hipEvent_t ev_start[kEvRing] = {}, ev_stop[kEvRing] = {};
     int ev_head = 0, ev_pending = 0;
+    unsigned char ev_tag[kEvRing] = {};    // 1 / 2: a trial launch of the streaming / the lock-step loop (see `trial` below)
+    // Frames of several passes per pixel (> 16 spp) have two kernels with bitwise the same output: lanes streaming through their
+    // samples (open scenes, where path lengths differ: plateau 3840x2160 spp 256 18.8 ms against 20.5) or the wave running pass by
+    // pass in lock-step (closed scenes, where nearly every path runs to the depth limit and regeneration only costs: cornell spp 64
+    // 4.42 ms against 4.9).  Which one is faster is a property of scene and frame that the host cannot see, but the launch times
+    // it takes anyway tell: the first four launches of a (scene, frame geometry, spp, mode) alternate between the two, the faster
+    // minimum keeps the job.
+    struct Trial {
+        std::vector<uint32_t> key;
+        int issued = 0, done = 0;
+        float best[2] = {1e30f, 1e30f};
+        int choice = -1;                   // 0 = streaming, 1 = lock-step, -1 = undecided
+    } trial;
     // scene
     uint32_t n_prims = 0;
     PrimIn* d_prims_in = nullptr;
@@ -45,6 +58,14 @@ struct rtgo_ctx {
     int n_fnodes = 0;             // nodes of the fast walk's tree
     int n_big_pairs = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};  // tight world bounds of the scene (min xyz, max xyz)
+    float* d_tight = nullptr;              // the fast walk's box of every primitive (device), and its host copy
+    std::vector<float> tight;
+    // per-strip mask of the scene's screen rectangle (LaunchParams::hot_mask), kept until the launch geometry changes
+    unsigned int* d_mask = nullptr;
+    size_t mask_capacity = 0;              // words
+    std::vector<uint32_t> mask_key;        // what the cached mask was built for
+    bool mask_all_hot = true;
+    unsigned long long mask_cold_pixels = 0;
     int leaf_budget = kDefaultLeafBudget;
     LightRec* d_lights = nullptr;
     int n_lights = 0;
@@ -96,19 +117,23 @@ static constexpr size_t kBuildDynLds = (size_t)2 * kMaxPrims * (6 * sizeof(float
 // every instantiation of the megakernel, in one place: rtgo_create raises the dynamic-LDS limit of each, rtgo_launch picks one
 using RenderKernel = void (*)(const LaunchParams, const float4*);
 struct RenderKernelEntry {
-    bool path, canon;
+    bool path, canon, stream;
     int wpe;
     RenderKernel fn;
 };
+#define RTGO_K(P, S, W, T) {P, S, T, W, render_kernel<P, S, W, T>}
 static const RenderKernelEntry kRenderKernels[] = {
-    {true, false, 4, render_kernel<true, false, 4>},   {true, false, 5, render_kernel<true, false, 5>},
-    {false, false, 4, render_kernel<false, false, 4>}, {false, false, 5, render_kernel<false, false, 5>},
-    {true, true, 4, render_kernel<true, true, 4>},     {false, true, 4, render_kernel<false, true, 4>},
+    RTGO_K(true, false, 4, false),  RTGO_K(true, false, 5, false),    // path mode, fast walk
+    RTGO_K(false, false, 4, false), RTGO_K(false, false, 5, false),   // distributed mode, fast walk
+    RTGO_K(true, false, 4, true),   RTGO_K(true, false, 5, true),     // ... more than 16 spp: lanes stream through their samples
+    RTGO_K(false, false, 4, true),  RTGO_K(false, false, 5, true),
+    RTGO_K(true, true, 4, false),   RTGO_K(false, true, 4, false),    // canonical walk (+ counters)
 };
-static RenderKernel find_kernel(bool path, bool canon, int wpe)
+#undef RTGO_K
+static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream)
 {
     for (const RenderKernelEntry& e : kRenderKernels)
-        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe)) return e.fn;
+        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe) && e.stream == (canon ? false : stream)) return e.fn;
     return nullptr;
 }
 
@@ -138,6 +163,12 @@ static int harvest_events(rtgo_ctx* c, int count)
         c->last_ms = ms;
         c->total_ms += ms;
         c->ev_pending--;
+        if (c->ev_tag[slot] != 0) {
+            float& best = c->trial.best[c->ev_tag[slot] - 1];
+            best = ms < best ? ms : best;
+            c->trial.done++;
+            c->ev_tag[slot] = 0;
+        }
     }
     return RTGO_OK;
 }
@@ -166,7 +197,7 @@ static unsigned int env_uint(const char* name, unsigned int dflt)
 // pinhole camera of the raygen program (d = dx*U + dy*V + W, kernel.cu:214-220; a sample of pixel (x, y) has dx, dy inside
 // that pixel's square).  Conservative: padded by two pixels, and the whole window whenever a corner is not in front of the
 // eye.  The kernel traces nothing for pixels outside it (their primary rays cannot reach the bounds: they are misses).
-static void scene_screen_rect(const rtgo_ctx* c, const LaunchParams& p, uint32_t& wx0, uint32_t& wx1, uint32_t& wy0, uint32_t& wy1)
+static void box_screen_rect(const float* bounds, const LaunchParams& p, uint32_t& wx0, uint32_t& wx1, uint32_t& wy0, uint32_t& wy1)
 {
     wx0 = 0;
     wy0 = 0;
@@ -184,7 +215,7 @@ static void scene_screen_rect(const rtgo_ctx* c, const LaunchParams& p, uint32_t
     if (uv * uv > tol * tol * uu * vv || uw * uw > tol * tol * uu * ww || vw * vw > tol * tol * vv * ww) return;
     double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
     for (int k = 0; k < 8; ++k) {
-        const double px = c->bounds[(k & 1) ? 3 : 0] - p.eye.x, py = c->bounds[(k & 2) ? 4 : 1] - p.eye.y, pz = c->bounds[(k & 4) ? 5 : 2] - p.eye.z;
+        const double px = bounds[(k & 1) ? 3 : 0] - p.eye.x, py = bounds[(k & 2) ? 4 : 1] - p.eye.y, pz = bounds[(k & 4) ? 5 : 2] - p.eye.z;
         const double a = (px * p.U.x + py * p.U.y + pz * p.U.z) / uu, b = (px * p.V.x + py * p.V.y + pz * p.V.z) / vv;
         const double w = (px * p.Wv.x + py * p.Wv.y + pz * p.Wv.z) / ww;
         if (!(w > 1e-3)) return;  // a corner beside or behind the eye: no useful rectangle
@@ -314,6 +345,8 @@ int rtgo_destroy(rtgo_ctx* c)
     }
     (void)hipFree(c->d_queue);
     (void)hipFree(c->d_counters);
+    (void)hipFree(c->d_tight);
+    (void)hipFree(c->d_mask);
     (void)hipFree(c->w_positions);
     (void)hipFree(c->w_normals);
     (void)hipFree(c->w_indices);
@@ -373,6 +406,10 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     (void)hipFree(c->d_prims);
     (void)hipFree(c->d_fnodes);
     (void)hipFree(c->d_fprims);
+    (void)hipFree(c->d_tight);
+    c->d_tight = nullptr;
+    c->mask_key.clear();
+    c->trial = rtgo_ctx::Trial();
     c->d_fnodes = nullptr;
     c->d_fprims = nullptr;
     c->d_prims_in = nullptr;
@@ -386,6 +423,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     RTGO_HIP(c, hipMalloc(&c->d_prims, n * 6 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->d_fnodes, (2 * n - 1) * 2 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->d_fprims, n * 4 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->d_tight, n * 6 * sizeof(float)));
     if (const char* k = std::getenv("RTGO_LEAF_BUDGET")) {  // tuning knob for experiments; results do not depend on it
         const int v = std::atoi(k);
         if (v >= 0 && v <= 16 * kMaxPrims) c->leaf_budget = v;
@@ -394,10 +432,12 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), kBuildDynLds, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
-                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta);
+                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight);
     RTGO_HIP(c, hipGetLastError());
     int meta[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
+    c->tight.assign((size_t)n * 6, 0.0f);
+    RTGO_HIP(c, hipMemcpyAsync(c->tight.data(), c->d_tight, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     const int depth = meta[0];
     c->lbvh_depth = depth;
@@ -536,7 +576,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     uint32_t wx0 = 0, wx1 = p.w, wy0 = 0, wy1 = p.h;
     // collect_stats 1: the instrumented kernel traces every pixel (V, T, h over ALL rays); 2: it culls like the timed
     // kernel, so that the counters describe the traversed rays only
-    if (f->collect_stats != 1 && !std::getenv("RTGO_NO_CULL")) scene_screen_rect(c, p, wx0, wx1, wy0, wy1);
+    const bool cull = f->collect_stats != 1 && !std::getenv("RTGO_NO_CULL");
+    if (cull) box_screen_rect(c->bounds, p, wx0, wx1, wy0, wy1);
     // The fast walk's tight boxes carry 1e-3 of padding against the rounding of the intersection programs, which grows with
     // the coordinates involved (~1e-7 of them for a rectangle's hit point).  Beyond 500 units -- the reference's scenes stay
     // within 20, its camera at 14 -- the launch takes the canonical walk instead: slower, and equal to it by definition.
@@ -582,6 +623,80 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (p.cold_cs == 0) p.cold_cs = 1;
     const uint32_t n_cold = (p.n_cold_segs + p.cold_cs - 1) / p.cold_cs;
     p.n_tiles = p.n_hot + n_cold;
+    // Inside the rectangle, strip by strip: does any primitive's own screen rectangle (its box as the fast walk culls with it,
+    // through the same pinhole projection, padded) reach the strip?  Scenes that do not fill their rectangle -- plateau: a plate and
+    // a few objects -- have most of it empty.  The mask depends on the launch geometry only; it is rebuilt when that changes.
+    p.hot_mask = nullptr;
+    unsigned long long mask_cold_pixels = 0;
+    if (cull && p.n_hot > 0 && !std::getenv("RTGO_NO_MASK")) {
+        std::vector<uint32_t> key = {p.W, p.H, p.x0, p.y0, p.w, p.h, p.band_h, p.n_ranks, p.rank, p.grab, strip_px, p.hot_x0, p.hot_y0, p.hot_w, p.hot_h};
+        const float cam[12] = {p.eye.x, p.eye.y, p.eye.z, p.U.x, p.U.y, p.U.z, p.V.x, p.V.y, p.V.z, p.Wv.x, p.Wv.y, p.Wv.z};
+        for (float v : cam) {
+            uint32_t bits;
+            std::memcpy(&bits, &v, 4);
+            key.push_back(bits);
+        }
+        const size_t words = ((size_t)p.n_hot + 31) / 32;
+        if (key != c->mask_key) {
+            std::vector<uint32_t> mask(words, 0u);
+            bool all_hot = false;
+            for (uint32_t i = 0; i < c->n_prims && !all_hot; ++i) {
+                uint32_t rx0, rx1, ry0, ry1;
+                box_screen_rect(&c->tight[6 * (size_t)i], p, rx0, rx1, ry0, ry1);
+                if (rx0 == 0 && rx1 == p.w && ry0 == 0 && ry1 == p.h) {   // a primitive whose rectangle is the whole window (or unknown)
+                    all_hot = true;
+                    break;
+                }
+                if (rx1 <= rx0 || ry1 <= ry0) continue;
+                const uint32_t sa = rx0 / strip_px, sb = (rx1 - 1) / strip_px;   // strip columns the rectangle touches
+                const uint32_t ca = sa > p.hot_x0 ? sa : p.hot_x0, cb = sb < p.hot_x0 + p.hot_w - 1 ? sb : p.hot_x0 + p.hot_w - 1;
+                if (ca > cb) continue;
+                for (uint32_t wrow = ry0; wrow < ry1; ++wrow) {
+                    if (p.n_ranks > 1 && (wrow / p.band_h) % p.n_ranks != p.rank) continue;
+                    const uint32_t lrow = owned_rows_below(wrow, p.band_h, p.n_ranks, p.rank);
+                    if (lrow < p.hot_y0 || lrow >= p.hot_y0 + p.hot_h) continue;
+                    const size_t base = (size_t)(lrow - p.hot_y0) * p.hot_w;
+                    for (uint32_t sc = ca; sc <= cb; ++sc) {
+                        const size_t bit = base + (sc - p.hot_x0);
+                        mask[bit >> 5] |= 1u << (bit & 31u);
+                    }
+                }
+            }
+            unsigned long long cold_px = 0;
+            if (!all_hot) {
+                size_t hot_bits = 0;
+                for (size_t b = 0; b < (size_t)p.n_hot; ++b) {
+                    if ((mask[b >> 5] >> (b & 31u)) & 1u) {
+                        ++hot_bits;
+                    } else {
+                        const uint32_t sc = p.hot_x0 + (uint32_t)(b % p.hot_w);
+                        const uint32_t xa = sc * strip_px, xb = xa + strip_px < p.w ? xa + strip_px : p.w;
+                        cold_px += xb > xa ? xb - xa : 0;
+                    }
+                }
+                all_hot = hot_bits == (size_t)p.n_hot;
+            }
+            if (!all_hot) {
+                if (words > c->mask_capacity) {
+                    (void)hipFree(c->d_mask);
+                    c->d_mask = nullptr;
+                    c->mask_capacity = 0;
+                    RTGO_HIP(c, hipMalloc(&c->d_mask, words * sizeof(uint32_t)));
+                    c->mask_capacity = words;
+                }
+                // (the previous launch may still be reading the old mask: stream order takes care of it)
+                RTGO_HIP(c, hipMemcpyAsync(c->d_mask, mask.data(), words * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+                RTGO_HIP(c, hipStreamSynchronize(c->stream));   // (the host vector goes out of scope; geometry changes are rare)
+            }
+            c->mask_all_hot = all_hot;
+            c->mask_cold_pixels = all_hot ? 0 : cold_px;
+            c->mask_key = key;
+        }
+        if (!c->mask_all_hot) {
+            p.hot_mask = c->d_mask;
+            mask_cold_pixels = c->mask_cold_pixels;
+        }
+    }
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
     p.fnodes = c->d_fnodes;
@@ -635,9 +750,44 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int max_wpe_work = units_per_wave4 >= 3 ? 5 : 4;
     int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);   // (experiment knob, clamped to what exists)
     max_wpe = max_wpe < 4 ? 4 : (max_wpe > 5 ? 5 : max_wpe);
+    // more than 16 spp = several passes per pixel: the streaming variant (render_kernel, STREAM) lets a lane start its next sample when
+    // its path has ended instead of waiting for the wave's longest path, pass after pass
+    bool stream = false;
+    unsigned char trial_tag = 0;
+    if (!canon && passes_of(nn) > 1) {
+        const char* force = std::getenv("RTGO_STREAM");   // "0" / "1": experiment and test knob, no trial
+        if (force) stream = force[0] != '0';
+        else {
+            rtgo_ctx::Trial& t = c->trial;
+            const std::vector<uint32_t> key = {p.W, p.H, p.x0, p.y0, p.w, p.h, p.band_h, p.n_ranks, p.rank, nn, (uint32_t)path, (uint32_t)f->max_trace_depth, (uint32_t)(f->use_ambient != 0)};
+            if (key != t.key) {
+                // (event tags of an unfinished trial of the old key stay where they are: they are counted into the old minima nobody reads)
+                t = rtgo_ctx::Trial();
+                t.key = key;
+                for (unsigned char& tag : c->ev_tag) tag = 0;
+            }
+            if (t.choice < 0 && t.issued >= 4) {
+                // all four are in flight or done: take what has finished, without waiting
+                while (c->ev_pending > 0) {
+                    const int slot = (c->ev_head - c->ev_pending + 2 * rtgo_ctx::kEvRing) % rtgo_ctx::kEvRing;
+                    if (hipEventQuery(c->ev_stop[slot]) != hipSuccess) break;
+                    const int rc = harvest_events(c, 1);
+                    if (rc) return rc;
+                }
+                (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error of this launch)
+                if (t.done >= 4) t.choice = t.best[0] <= t.best[1] ? 0 : 1;
+            }
+            if (t.choice >= 0) stream = t.choice == 0;
+            else if (t.issued < 4) {
+                stream = (t.issued & 1) == 0;
+                trial_tag = stream ? 1 : 2;
+                t.issued++;
+            } else stream = true;   // results pending
+        }
+    }
     for (int w = 4; w <= max_wpe; ++w)
         for (int b = 256; b <= kMaxBlock; b *= 2) {
-            const size_t l = scene_lds + (size_t)p.stack_depth * b * (canon ? sizeof(float2) : sizeof(unsigned int)) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
+            const size_t l = scene_lds + (stream ? (size_t)(b / 64) * 192 * kStreamWindow * sizeof(float) : 0) + (size_t)p.stack_depth * b * (canon ? sizeof(float2) : sizeof(unsigned int)) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
             int per_cu = (int)((160 * 1024) / l);
             if (per_cu * (b / 64) > 4 * w) per_cu = (4 * w) / (b / 64);
             const int waves = per_cu * (b / 64);
@@ -668,15 +818,16 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         if (rc) return rc;
     }
     const int slot = c->ev_head;
+    c->ev_tag[slot] = trial_tag;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const float4* fp = (const float4*)c->d_fprims;
-    const RenderKernel kernel = find_kernel(path, canon, wpe);
+    const RenderKernel kernel = find_kernel(path, canon, wpe, stream);
     if (!kernel) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: no kernel variant for this configuration");
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->queue_set = 1 - c->queue_set;
-    c->rays_culled += ((unsigned long long)p.local_rows * p.w - (unsigned long long)p.hot_h * (p.cold_x1 - p.cold_x0)) * nn;
+    c->rays_culled += ((unsigned long long)p.local_rows * p.w - (unsigned long long)p.hot_h * (p.cold_x1 - p.cold_x0) + mask_cold_pixels) * nn;
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;
     c->ev_pending++;
     c->launches++;

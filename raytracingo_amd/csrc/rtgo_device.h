@@ -76,6 +76,10 @@ struct LaunchParams {
     unsigned int segs_full, segs_l, segs_r;   // 64-pixel segments per full row, per row left / right of the rectangle
     unsigned int n_cold_segs, cold_cs;
     unsigned int grab;               // units per strip (1..kUnitsPerGrab, strip <= 64 pixels)
+    // One bit per strip of the rectangle (bit = strip index, row-major): 0 = no primitive's screen rectangle reaches the strip, so
+    // its pixels are background like those outside the rectangle and are written without tracing.  Null when every strip is hot
+    // (scenes that fill their rectangle: nothing to look up then).
+    const unsigned int* hot_mask;
 #ifdef RTGO_TIMELINE
     unsigned long long* timeline;    // diagnostic build: 8 words per wave, see tools/timeline.py
 #endif
@@ -786,7 +790,9 @@ __device__ __forceinline__ void cold_segment(const LaunchParams& p, unsigned int
 // WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs) for scenes whose LDS image limits a CU to 16 waves
 // anyway, 5 (<= 96 VGPRs, per-level path records in LDS) for small scenes, where the fifth wave buys more than the tighter
 // budget costs (rtgo_capi.hip picks per launch; kRenderKernels there lists every instantiation).
-template <bool PATH, bool STATS, int WPE>
+constexpr int kStreamWindow = 4;   // STREAM: passes a lane may run ahead of the oldest pass that is still open (192 floats of LDS per wave each)
+
+template <bool PATH, bool STATS, int WPE, bool STREAM>
 __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -813,6 +819,8 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     // registers through the ray loop
     float* s_cam = reinterpret_cast<float*>(s_lights + kMaxLights);
     float* s_lv = s_cam + 16 + threadIdx.x;
+    // STREAM: the payload window of this wave (4 passes x 3 channels x 64 lanes), behind the level records
+    float* s_win_base = s_cam + 16 + (LVLDS ? (int)blockDim.x * LVW * kMaxLevels : 0) + 192 * kStreamWindow * (threadIdx.x >> 6);
 
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid < kQueues) p.queue_next[kQueueStride * (unsigned int)tid] = 0u;
@@ -932,6 +940,15 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         }
         const unsigned int lr = p.hot_y0 + strip / p.hot_w;   // local (compact) row
         const unsigned int sx = p.hot_x0 + (strip - (lr - p.hot_y0) * p.hot_w);   // strip column
+        if (p.hot_mask != nullptr && ((p.hot_mask[strip >> 5] >> (strip & 31u)) & 1u) == 0u) {
+            // a strip of the rectangle that no primitive's own screen rectangle reaches (the word is wave-uniform: a scalar load)
+            const unsigned int lx0 = sx * p.grab * P + (unsigned int)lane;
+            if ((unsigned int)lane < p.grab * P && lx0 < p.w) {
+                write_pixel(p, (size_t)lr * p.w + lx0, p.bg_pixel);
+                c_rays += nn;
+            }
+            continue;
+        }
         // local row -> window row under the band interleave
         const unsigned int band = lr / p.band_h;
         const unsigned int wrow = (band * p.n_ranks + p.rank) * p.band_h + (lr - band * p.band_h);
@@ -953,39 +970,26 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         // __raygen__rg (kernel.cu:184-247)
         const unsigned int pix0 = (unsigned int)__shfl((int)strip_seed, (int)((ui * P + pl) & 63u), 64);
         v3 color = mk(0.0f, 0.0f, 0.0f);
+        if constexpr (!STREAM) {
 #pragma unroll 1
         for (unsigned int pass = 0; pass < passes; ++pass) {
         const unsigned int k = pass * nn_eff + kl;   // sample index: i-major, k = i*N + j (kernel.cu:206-208)
-        bool active = in_range && k < nn;
-        int depth = 0;
-        int phase = 0;                 // distributed mode: 0 = radiance ray in flight, 1 = shadow ray in flight
-        // start sample k: kernel.cu:210-231; x jitter drawn first.  Draws 2k and 2k+1 of the pixel's stream.
-        unsigned int seed = lcg_skip(pix0, 2u * k);
-        const unsigned int si = k / (unsigned int)p.sqrt_spp, sj = k - si * (unsigned int)p.sqrt_spp;
-        const float r0 = rnd(seed);
-        const float r1 = rnd(seed);
-        const float4 cam0 = reinterpret_cast<const float4*>(s_cam)[0], cam1 = reinterpret_cast<const float4*>(s_cam)[1],
-                     cam2 = reinterpret_cast<const float4*>(s_cam)[2], cam3 = reinterpret_cast<const float4*>(s_cam)[3];
-        const float inc = cam2.w;
-        const float dx = 2.0f * ((fx + ((float)si + r0) * inc) / cam0.w) - 1.0f;
-        const float dy = 2.0f * ((fy + ((float)sj + r1) * inc) / cam1.w) - 1.0f;
-        v3 ro = mk(cam0.x, cam0.y, cam0.z);
-        v3 rd = vnormalize(vadd(vadd(vscale(mk(cam1.x, cam1.y, cam1.z), dx), vscale(mk(cam2.x, cam2.y, cam2.z), dy)), mk(cam3.x, cam3.y, cam3.z)));
-        float tmin = 0.05f, tmax = 1e16f;
-        v3 result = mk(0.0f, 0.0f, 0.0f);   // payload of this sample's primary ray
-        bool any_hit = false;
+        bool active;
+        int depth;
+        int phase;                     // distributed mode: 0 = radiance ray in flight, 1 = shadow ray in flight
+        unsigned int seed;
+        v3 ro, rd;
+        float tmin, tmax;
+        v3 result;                     // payload of this sample's primary ray
+        bool any_hit;
         // per-level records, folded innermost-first when the path ends
         v3 lvA[kMaxLevels];            // PATH: w_k = dot(N,Ra)*kd ; distributed: a_k = falloff*diffuse
         int lvPrim[kMaxLevels];        // distributed: primitive of level k (kr, kd re-read at fold time)
-#pragma unroll
-        for (int q = 0; q < kMaxLevels; ++q) {
-            lvA[q] = mk(0, 0, 0);
-            lvPrim[q] = 0;
-        }
         // distributed: state kept across the shadow ray
-        v3 sN = mk(0, 0, 0), sRr = mk(0, 0, 0);
-        float sDist = 0.0f;
-        int sPrim = 0, sLight = 0;
+        v3 sN, sRr;
+        float sDist;
+        int sPrim, sLight;
+#include "rtgo_start_sample.inc"
 
 #ifdef RTGO_TIMELINE
         if (tl_units++ == 0) tl_first = wall_clock64();
@@ -1002,205 +1006,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
             tl_lanes += (unsigned long long)__popcll(__ballot(active));
 #endif
             if (active) {
-                Hit h;
-                c_rays += 1;
-                bool hit;
-                if constexpr (STATS) hit = closest_hit<true>(s_nodes, s_prims, s_stack, bshift, ro, rd, tmin, tmax, h, c_nodes, c_tests);
-                else hit = closest_hit_fast(s_nodes, s_prims, g_fprims, s_stack4, bshift, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, h, c_nodes, c_tests
-#ifdef RTGO_TIMELINE
-                                            , tl_big, tl_tree
-#endif
-                );
-                if (STATS && hit) c_hits += 1;
-                any_hit = any_hit || hit;
-#ifdef RTGO_CMPWALK
-                if constexpr (STATS) {
-                    // diagnostic build (tools/cmp_walks.py): the fast walk on the same ray, straight from global memory
-                    Hit hf;
-                    unsigned int d0 = 0, d1 = 0;
-                    // (this lane's canonical stack is idle here: its own 8-byte slots serve as the fast walk's one-word entries)
-                    const bool hitf = closest_hit_fast(p.fnodes, p.fprims, p.fprims, reinterpret_cast<unsigned int*>(s_stack), bshift + 1, p.n_small, p.n_prims, p.n_big_pairs, ro, rd, tmin, tmax, hf, d0, d1);
-                    const bool same = hit == hitf && (!hit || (h.t == hf.t && h.prim == hf.prim && h.n.x == hf.n.x && h.n.y == hf.n.y && h.n.z == hf.n.z));
-                    if (!same) {
-                        const unsigned int slot = atomicAdd(reinterpret_cast<unsigned int*>(p.cmp), 1u);
-                        if (slot < 255u) {
-                            float* r = p.cmp + 16 * (slot + 1);
-                            r[0] = ro.x; r[1] = ro.y; r[2] = ro.z; r[3] = rd.x; r[4] = rd.y; r[5] = rd.z; r[6] = tmin; r[7] = tmax;
-                            r[8] = hit ? h.t : -1.0f; r[9] = hit ? (float)h.prim : -1.0f; r[10] = hitf ? hf.t : -1.0f; r[11] = hitf ? (float)hf.prim : -1.0f;
-                            r[12] = (float)depth; r[13] = (float)phase; r[14] = 0.0f; r[15] = 0.0f;
-                        }
-                    }
-                }
-#endif
-
-                bool done = false;       // path ended: `term` is the payload of the ray at level `depth`
-                v3 term = mk(0, 0, 0);
-
-                if (PATH) {
-                    if (!hit) {
-                        term = p.bg;  // __miss__ms, kernel.cu:419-423
-                        done = true;
-                    } else {
-                        // __closesthit__ch, path branch: kernel.cu:426-475
-                        const float4 m3 = s_mat[MS * h.prim + 0], m5 = s_mat[MS * h.prim + 2];
-                        v3 N = vnormalize(h.n);
-                        const float t = h.t;
-                        const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
-                        const v3 x = vadd(ro, vscale(vnormalize(rd), t));
-                        if (faces_away(N, vsub(ro, x))) N = vscale(N, -1.0f);
-                        if (m5.x > 0.01f) {
-                            term = mk(m5.x, m5.y, m5.z);
-                            done = true;
-                        } else if (depth < p.max_depth) {
-                            const v3 Ra = hemisphere(N, N, 0.0f, seed);
-                            const v3 wk = vadd(mk(0.0f, 0.0f, 0.0f), vscale(mk(m3.x, m3.y, m3.z), vdot(N, Ra)));
-                            if constexpr (LVLDS) {
-                                s_lv[(depth * LVW + 0) << bshift] = wk.x;
-                                s_lv[(depth * LVW + 1) << bshift] = wk.y;
-                                s_lv[(depth * LVW + 2) << bshift] = wk.z;
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < kMaxLevels; ++k)
-                                    if (k == depth) lvA[k] = wk;
-                            }
-                            ++depth;
-                            ro = x;
-                            rd = Ra;
-                            tmin = rayEpsilon;
-                            tmax = 1e6f;
-                        } else {
-                            term = mk(0.0f, 0.0f, 0.0f);
-                            done = true;
-                        }
-                    }
-                } else {
-                    if (phase == 1) {
-                        // back from the shadow ray: kernel.cu:498-535 (+ __closesthit__full_occlusion :539-549)
-                        c_occl += 1;
-                        v3 illum = mk(1.0f, 1.0f, 1.0f);  // occlusion miss leaves the payload untouched
-                        if (hit) {
-                            const float4 b5 = s_mat[MS * h.prim + 2];
-                            illum = mk(fminf(b5.x, 1.0f), fminf(b5.y, 1.0f), fminf(b5.z, 1.0f));
-                        }
-                        const LightRec& L = s_lights[sLight];
-                        const float4 m3 = s_mat[MS * sPrim + 0];
-                        const v3 kd = mk(m3.x, m3.y, m3.z);
-                        const float spec = m3.w;
-                        const v3 Lm = rd;
-                        const v3 lightNormal = mk(L.normal[0], L.normal[1], L.normal[2]);
-                        const v3 lightColor = vscale(illum, fabsf(vdot(Lm, lightNormal)));
-                        const float falloff = 1.0f / (1.0f + L.falloff * sDist);
-                        const v3 compDiffuse =
-                            vmul(vscale(lightColor, fmaxf(vdot(sN, Lm), 0.0f)), kd);   // (kernel.cu:503 tests dot(N, V) < 0 again: after the flip it never is)
-                        const v3 a = vadd(mk(0.0f, 0.0f, 0.0f), vscale(compDiffuse, falloff));
-                        bool bounce = false;
-                        v3 r = mk(0, 0, 0);
-                        if (depth < p.max_depth) {
-                            if (p.ambient) {
-                                if (spec > 0.5f) {
-                                    r = hemisphere(sN, sRr, spec, seed);
-                                    bounce = true;
-                                }
-                            } else {
-                                r = spec < 0.5f ? hemisphere(sN, sN, 0.0f, seed) : hemisphere(sN, sRr, spec, seed);
-                                bounce = true;
-                            }
-                        }
-                        if (bounce) {
-                            if constexpr (LVLDS) {
-                                s_lv[(depth * LVW + 0) << bshift] = a.x;
-                                s_lv[(depth * LVW + 1) << bshift] = a.y;
-                                s_lv[(depth * LVW + 2) << bshift] = a.z;
-                                s_lv[(depth * LVW + 3) << bshift] = __int_as_float(sPrim);
-                            } else {
-#pragma unroll
-                                for (int k = 0; k < kMaxLevels; ++k)
-                                    if (k == depth) {
-                                        lvA[k] = a;
-                                        lvPrim[k] = sPrim;
-                                    }
-                            }
-                            ++depth;
-                            rd = r;            // ro = x and tmin = rayEpsilon are still those of the shadow ray
-                            tmax = 1e6f;
-                            phase = 0;
-                        } else {
-                            term = a;
-                            if (p.ambient && depth < p.max_depth) term = vadd(term, vmul(kd, mk(0.1f, 0.1f, 0.1f)));
-                            done = true;
-                        }
-                    } else if (!hit) {
-                        term = p.bg;
-                        done = true;
-                    } else {
-                        // __closesthit__ch, distributed branch up to the shadow trace: kernel.cu:426-455, 477-499
-                        const float4 m5 = s_mat[MS * h.prim + 2];
-                        v3 N = vnormalize(h.n);
-                        const float t = h.t;
-                        const float rayEpsilon = 1e-6f * fmaxf(t * t, 1.0f);
-                        const v3 dn = vnormalize(rd);
-                        const v3 x = vadd(ro, vscale(dn, t));
-                        if (faces_away(N, vsub(ro, x))) N = vscale(N, -1.0f);
-                        if (vlength(mk(m5.x, m5.y, m5.z)) > 0.01f) {
-                            term = mk(1.0f, 1.0f, 1.0f);
-                            done = true;
-                        } else {
-                            const int l = (int)(rnd(seed) * (float)(p.n_lights - 1));
-                            const LightRec& L = s_lights[l];
-                            const float ra = rnd(seed);  // Q1: v1 factor first
-                            const float rb = rnd(seed);
-                            const v3 samplingPos =
-                                vadd(vadd(mk(L.corner[0], L.corner[1], L.corner[2]), vscale(mk(L.v1[0], L.v1[1], L.v1[2]), ra)),
-                                     vscale(mk(L.v2[0], L.v2[1], L.v2[2]), rb));
-                            const v3 toL = vsub(samplingPos, x);
-                            const v3 Lm = vnormalize(toL);
-                            const float lightDistance = vlength(toL);
-                            const v3 omega = vneg(dn);
-                            sRr = vadd(vneg(omega), vscale(N, 2.0f * vdot(N, omega)));
-                            sN = N;
-                            sDist = lightDistance;
-                            sPrim = h.prim;
-                            sLight = l;
-                            ro = x;
-                            rd = Lm;
-                            tmin = rayEpsilon;
-                            tmax = lightDistance - rayEpsilon;
-                            phase = 1;
-                        }
-                    }
-                }
-
-                if (done) {
-                    // fold the level records innermost-first: kernel.cu:471-472 (path), :504,519,531 (distributed)
-                    if constexpr (LVLDS) {
-                        for (int k = depth - 1; k >= 0; --k) {
-                            const v3 a = mk(s_lv[(k * LVW + 0) << bshift], s_lv[(k * LVW + 1) << bshift], s_lv[(k * LVW + 2) << bshift]);
-                            if (PATH) {
-                                term = vmul(a, term);
-                            } else {
-                                const int prim = __float_as_int(s_lv[(k * LVW + 3) << bshift]);
-                                const float4 m3 = s_mat[MS * prim + 0], m4 = s_mat[MS * prim + 1];
-                                term = vadd(a, vmul(mk(m4.x, m4.y, m4.z), term));
-                                if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = kMaxLevels - 1; k >= 0; --k) {
-                            if (k < depth) {
-                                if (PATH) {
-                                    term = vmul(lvA[k], term);
-                                } else {
-                                    const float4 m3 = s_mat[MS * lvPrim[k] + 0], m4 = s_mat[MS * lvPrim[k] + 1];
-                                    term = vadd(lvA[k], vmul(mk(m4.x, m4.y, m4.z), term));
-                                    if (p.ambient) term = vadd(term, vmul(mk(m3.x, m3.y, m3.z), mk(0.1f, 0.1f, 0.1f)));
-                                }
-                            }
-                        }
-                    }
-                    result = term;
-                    active = false;
-                }
+#include "rtgo_ray_step.inc"
             }
 #ifdef RTGO_TIMELINE
             tl_loop += wall_clock64() + (result.x == 12345.0f ? 1 : 0) - tl_i0;
@@ -1218,6 +1024,83 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
             }
         }
         }  // pass
+        } else {
+            // STREAM (frames of more than 16 spp: several passes per pixel).  In open scenes most paths end after a ray or two while a
+            // few go on for six: run pass by pass in lock-step, the wave would trace four more iterations for a handful of lanes,
+            // sixteen times per pixel at 256 spp.  Here a lane whose path has ended starts its NEXT sample (same pixel, next pass)
+            // while the others go on -- wavefront compaction in time rather than across lanes: no state moves, the lane keeps its
+            // registers.  New samples start in batches (>= kRegenBatch idle lanes, found by __ballot, or nobody active) so that the
+            // raygen code runs with lanes to fill it.  The payloads wait in a window of kWin passes in LDS and are added pass by
+            // pass, in sample order (kernel.cu:232), as soon as every sample of the oldest open pass has ended.
+            constexpr unsigned int kWin = (unsigned int)kStreamWindow, kRegenBatch = 4u;
+            float* s_win = s_win_base;
+            unsigned int my_pass = 0u, fold_pass = 0u;
+        bool active;
+        int depth;
+        int phase;                     // distributed mode: 0 = radiance ray in flight, 1 = shadow ray in flight
+        unsigned int seed;
+        v3 ro, rd;
+        float tmin, tmax;
+        v3 result;                     // payload of this sample's primary ray
+        bool any_hit;
+        // per-level records, folded innermost-first when the path ends
+        v3 lvA[kMaxLevels];            // PATH: w_k = dot(N,Ra)*kd ; distributed: a_k = falloff*diffuse
+        int lvPrim[kMaxLevels];        // distributed: primitive of level k (kr, kd re-read at fold time)
+        // distributed: state kept across the shadow ray
+        v3 sN, sRr;
+        float sDist;
+        int sPrim, sLight;
+            active = false;
+            depth = 0;
+            phase = 0;
+            seed = 0u;
+            ro = rd = result = sN = sRr = mk(0, 0, 0);
+            tmin = tmax = sDist = 0.0f;
+            any_hit = false;
+            sPrim = sLight = 0;
+#pragma unroll
+            for (int q = 0; q < kMaxLevels; ++q) {
+                lvA[q] = mk(0, 0, 0);
+                lvPrim[q] = 0;
+            }
+            for (;;) {
+                const bool idle = !active && in_range && (my_pass * nn_eff + kl) < nn && my_pass < fold_pass + kWin;
+                const unsigned long long m_idle = __ballot(idle), m_act = __ballot(active);
+                if (m_idle != 0ull && (m_act == 0ull || (unsigned int)__popcll(m_idle) >= kRegenBatch)) {
+                    if (idle) {
+                        const unsigned int k = my_pass * nn_eff + kl;
+#include "rtgo_start_sample.inc"
+                    }
+                }
+                if (__ballot(active) != 0ull) {
+                    const bool was = active;
+                    if (active) {
+#include "rtgo_ray_step.inc"
+                    }
+                    if (was && !active) {
+                        const unsigned int slot = (my_pass % kWin) * 192u + (unsigned int)lane;
+                        s_win[slot] = result.x;
+                        s_win[slot + 64u] = result.y;
+                        s_win[slot + 128u] = result.z;
+                        ++my_pass;
+                    }
+                }
+                while (fold_pass < passes) {
+                    // a lane still owes the oldest open pass while it has a sample there that has not ended
+                    const bool owes = in_range && (fold_pass * nn_eff + kl) < nn && my_pass <= fold_pass;
+                    if (__ballot(owes) != 0ull) break;
+                    const unsigned int cnt = (nn - fold_pass * nn_eff) < nn_eff ? (nn - fold_pass * nn_eff) : nn_eff;
+                    const unsigned int slot = (fold_pass % kWin) * 192u;
+                    for (unsigned int q = 0; q < cnt; ++q) {
+                        const unsigned int src = slot + group_base + q;
+                        color = vadd(color, mk(s_win[src], s_win[src + 64u], s_win[src + 128u]));
+                    }
+                    ++fold_pass;
+                }
+                if (fold_pass >= passes) break;
+            }
+        }
+
 
         if (in_range && kl == 0) {
             // kernel.cu:236-246.  float3 / float multiplies by the reciprocal (vec_math.h:479-483)
@@ -1359,12 +1242,14 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
 // Outputs.  out_nodes: (2n-1) x 2 float4 canonical LBVH; out_prims: n x 6 float4 (SBT order); aabb_io: n x 6 floats (read when
 // have_aabb, else written); out_fnodes / out_fprims: the fast walk's tree (2*n_small-1 nodes) and Morton-ordered records
 // (small primitives first, then the "big" ones that are tested up front);
+// out_tight: n x 6 floats, the fast walk's box of every primitive (SBT order);
 // out_meta = {canonical depth, fast-walk stack depth, n_small, tight scene bounds (6 floats as bits), pairs in the up-front list,
 // nodes of the fast walk's tree}.
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
-                                                          float4* __restrict__ out_fprims, int leaf_budget, float big_frac, int* __restrict__ out_meta)
+                                                          float4* __restrict__ out_fprims, int leaf_budget, float big_frac, int* __restrict__ out_meta,
+                                                          float* __restrict__ out_tight)
 {
     __shared__ float s_box[kMaxPrims][6];               // per primitive: reference AABB, later the tight box
     __shared__ unsigned long long s_keys[kMaxPrims];
@@ -1575,6 +1460,8 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         }
     }
     __syncthreads();
+    if (i < n)   // per primitive: the box the fast walk culls with (the host projects these onto the screen: LaunchParams::hot_mask)
+        for (int a = 0; a < 6; ++a) out_tight[6 * i + a] = s_box[i][a];
     reduce_bounds(i < n);
     if (i < 6) out_meta[3 + i] = __float_as_int(s_red[i][0]);  // tight scene bounds: min xyz, max xyz
     bool big = false;

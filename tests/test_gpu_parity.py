@@ -513,6 +513,30 @@ def test_odd_sample_counts_and_tiny_images(capi, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [("plateau", 16, True), ("cornell", 5, True), ("mirror_spheres", 8, True), ("cornell", 6, False), ("slide", 7, False)])
+def test_streaming_and_lock_step_loops_are_bitwise_the_same(capi, oracle, case, monkeypatch):
+    """frames of more than 16 spp have two kernels (lanes streaming through their samples / the wave in lock-step, pass by pass):
+    both must give the oracle's frame, bit for bit the same as each other -- and so must whatever the launch-time trial between
+    them picks (launches 0-3 of a configuration alternate, later ones use the faster)"""
+    name, n, path = case
+    W, H = 112, 63
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    racc, rimg, rc = oracle.render(sc, oracle.frame(W, H, n, 3, path=path, mode=1))
+    out = {}
+    for force in ("1", "0"):
+        monkeypatch.setenv("RTGO_STREAM", force)
+        ctx.reset_stats()
+        out[force] = gpu_render(capi, ctx, W, H, n, 3, path, prev=np.zeros((H, W, 4), np.float32))
+        assert_parity(out[force][0], racc, out[force][1], rimg, what="%s N=%d RTGO_STREAM=%s" % (name, n, force))
+    assert np.array_equal(out["1"][0].view(np.uint32), out["0"][0].view(np.uint32)) and np.array_equal(out["1"][1], out["0"][1])
+    monkeypatch.delenv("RTGO_STREAM")
+    for launch in range(7):
+        acc, img = gpu_render(capi, ctx, W, H, n, 3, path, prev=np.zeros((H, W, 4), np.float32))
+        assert np.array_equal(acc.view(np.uint32), out["0"][0].view(np.uint32)) and np.array_equal(img, out["0"][1]), launch
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cornell", "plateau", "mirror_spheres", "slide"])
 def test_background_culling_random_cameras(capi, oracle, name):
     """The timed kernel traces nothing for pixels outside the screen rectangle of the scene's bounds (their primary rays are
