@@ -376,7 +376,6 @@ __device__ __forceinline__ bool closest_hit(const float4* __restrict__ s_nodes, 
 // =====================================================================================================================
 struct FastHit {
     float t;
-    v3 nobj;   // object-space normal of the winner when it is a sphere or a cylinder (kernel.cu:270,315 before TransformNormal)
     int pos;   // Morton position of the winner | kFlat when it is a rectangle or a disk (object-space normal (0,1,0): kernel.cu:345,388)
     int orig;  // its SBT index (tie-break + material lookup)
 };
@@ -435,7 +434,6 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
             const float t = (-b - sdiscr) / (2.0f * a);
             if (t > 0.0001f && closer(t, orig, tmin, best)) {
                 best.t = t;
-                best.nobj = vnormalize(vadd(o, vscale(d, t)));
                 best.pos = pos;
                 best.orig = orig;
             }
@@ -467,7 +465,6 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
             }
             if (valid && closer(t, orig, tmin, best)) {
                 best.t = t;
-                best.nobj = mk(o.x + t * d.x, 0.0f, o.z + t * d.z);
                 best.pos = pos;
                 best.orig = orig;
             }
@@ -549,8 +546,10 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
     return tn <= tf * 1.000002f + 1e-7f;
 }
 
+
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 const float4* __restrict__ g_fprims, unsigned int* __restrict__ s_stack, int bshift,
+                                                 const float4* __restrict__ g_fprims,
+ unsigned int* __restrict__ s_stack, int bshift,
                                                  int n_small, int n_prims, int n_big_pairs, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests
 #ifdef RTGO_TIMELINE
@@ -563,7 +562,6 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
 #endif
     FastHit best;
     best.t = tmax;
-    best.nobj = mk(0.0f, 0.0f, 0.0f);
     best.pos = -1;
     best.orig = -1;
     out.prim = -1;
@@ -655,7 +653,17 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     const bool flat = (best.pos & kFlat) != 0;
     const float4 r0 = s_fprims[4 * wpos + 0], r1 = s_fprims[4 * wpos + 1], r2 = s_fprims[4 * wpos + 2];
     out.t = best.t;
-    out.n = xf_normal(r0, r1, r2, flat ? mk(0.0f, 1.0f, 0.0f) : best.nobj);
+    // the object-space normal of the winner only (kernel.cu:270 sphere, :315 cylinder, :345/:388 disk and rectangle), from the same
+    // object-space ray and the same t as its test: candidates that were overtaken never needed one
+    v3 nobj = mk(0.0f, 1.0f, 0.0f);
+    if (!flat) {
+        const v3 od = xf_dir(r0, r1, r2, d);
+        const v3 oo = xf_point(r0, r1, r2, o);
+        const bool sphere = __float_as_int(s_fprims[4 * wpos + 3].x) == 3;
+        const v3 at = sphere ? vadd(oo, vscale(od, best.t)) : mk(oo.x + best.t * od.x, 0.0f, oo.z + best.t * od.z);
+        nobj = sphere ? vnormalize(at) : at;
+    }
+    out.n = xf_normal(r0, r1, r2, nobj);
     out.prim = best.orig;
     return true;
 }
