@@ -99,7 +99,11 @@ struct rtgo_ctx {
     whitted::Pbr* w_materials = nullptr;
     whitted::PointLight* w_lights = nullptr;
     float4* w_nodes = nullptr;
+    float4* w_recs = nullptr;              // the walk's records (4 float4 each) and the triangles in Morton order (3 float4 each)
+    float4* w_tris = nullptr;
     int* w_scratch = nullptr;
+    unsigned int* w_tile_counters = nullptr;   // two sets of tile-queue heads: a launch counts on one and zeroes the other
+    int w_n_recs = 0, w_walk_depth = 0, w_launch_parity = 0;
     int w_triangles = 0, w_n_lights = 0, w_n_materials = 0;
     v3 w_miss{0, 0, 0};
     std::string err;
@@ -315,6 +319,8 @@ int rtgo_create(int device, rtgo_ctx** out)
         if (err == hipSuccess) err = hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     // (the build kernel holds ~58 KB of static LDS; its dynamic part is the fast walk's tree under construction)
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildDynLds);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess) err = hipDeviceSynchronize();  // the null-stream memsets above must land before any launch
     if (err != hipSuccess) {
         std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
@@ -353,7 +359,10 @@ int rtgo_destroy(rtgo_ctx* c)
     (void)hipFree(c->w_tri_material);
     (void)hipFree(c->w_materials);
     (void)hipFree(c->w_lights);
+    (void)hipFree(c->w_tile_counters);
     (void)hipFree(c->w_nodes);
+    (void)hipFree(c->w_recs);
+    (void)hipFree(c->w_tris);
     (void)hipFree(c->w_scratch);
     for (int i = 0; i < rtgo_ctx::kEvRing; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
@@ -883,11 +892,14 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     (void)hipFree(c->w_tri_material);
     (void)hipFree(c->w_materials);
     (void)hipFree(c->w_nodes);
+    (void)hipFree(c->w_recs);
+    (void)hipFree(c->w_tris);
     (void)hipFree(c->w_scratch);
     c->w_positions = c->w_normals = nullptr;
     c->w_indices = c->w_tri_material = nullptr;
     c->w_materials = nullptr;
     c->w_nodes = nullptr;
+    c->w_recs = c->w_tris = nullptr;
     c->w_scratch = nullptr;
     c->w_triangles = 0;
     const size_t vb = (size_t)n_vertices * 3 * sizeof(float), ib = (size_t)n_triangles * 3 * sizeof(unsigned int);
@@ -906,19 +918,35 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     RTGO_HIP(c, hipMalloc(&c->w_materials, (size_t)n_materials * sizeof(whitted::Pbr)));
     RTGO_HIP(c, hipMemcpyAsync(c->w_materials, materials, (size_t)n_materials * sizeof(whitted::Pbr), hipMemcpyHostToDevice, c->stream));
     RTGO_HIP(c, hipMalloc(&c->w_nodes, (size_t)(2 * n_triangles - 1) * 2 * sizeof(float4)));
-    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(3 * n_triangles + 8) * sizeof(int)));   // parent [2n-1], visit [n], meta
+    RTGO_HIP(c, hipMalloc(&c->w_recs, (size_t)n_triangles * 4 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->w_tris, (size_t)n_triangles * 3 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(6 * n_triangles + 8) * sizeof(int)));   // parent [2n-1], visit, first, count, record [n each], meta
     int* parent = c->w_scratch;
     int* visit = parent + (2 * n_triangles - 1);
-    int* meta = visit + n_triangles;
+    int* first_of = visit + n_triangles;
+    int* count_of = first_of + n_triangles;
+    int* rec_of = count_of + n_triangles;
+    int* meta = rec_of + n_triangles;
     hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), 0, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
-                       parent, visit, meta);
+                       parent, visit, first_of, count_of, rec_of, c->w_recs, c->w_tris, meta);
     RTGO_HIP(c, hipGetLastError());
-    int depth = 0;
-    RTGO_HIP(c, hipMemcpyAsync(&depth, meta, sizeof depth, hipMemcpyDeviceToHost, c->stream));
+    int m[3] = {0, 0, 0};
+    RTGO_HIP(c, hipMemcpyAsync(m, meta, sizeof m, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
-    if (depth > whitted::kStack)
-        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_mesh: triangle LBVH depth " + std::to_string(depth) + " exceeds the traversal stack (" +
+    if (m[0] > whitted::kStack)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_mesh: triangle LBVH depth " + std::to_string(m[0]) + " exceeds what the build handles (" +
                                                std::to_string(whitted::kStack) + ")");
+    if (m[2] > whitted::kMaxWalkDepth)
+        return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_mesh: the walk needs " + std::to_string(m[2]) + " stack entries (limit " +
+                                               std::to_string(whitted::kMaxWalkDepth) + ")");
+    c->w_n_recs = m[1];
+    c->w_walk_depth = m[2] < 1 ? 1 : m[2];
+    if (!c->w_tile_counters) {
+        const size_t heads_bytes = 2 * (size_t)whitted::kTileHeads * whitted::kTileHeadStride * sizeof(unsigned int);
+        RTGO_HIP(c, hipMalloc(&c->w_tile_counters, heads_bytes));
+        RTGO_HIP(c, hipMemsetAsync(c->w_tile_counters, 0, heads_bytes, c->stream));
+        RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->w_triangles = (int)n_triangles;
     c->w_n_materials = (int)n_materials;
     return RTGO_OK;
@@ -955,7 +983,23 @@ int rtgo_whitted_launch(rtgo_ctx* c, uint32_t width, uint32_t height, uint32_t s
     if (!c->w_lights) RTGO_HIP(c, hipMalloc(&c->w_lights, RTGO_MAX_LIGHTS * sizeof(whitted::PointLight)));
     whitted::Params p;
     std::memset(&p, 0, sizeof p);
-    p.nodes = c->w_nodes;
+    p.recs = c->w_recs;
+    p.tris = c->w_tris;
+    p.n_recs = c->w_n_recs;
+    p.stack_depth = c->w_walk_depth;
+    p.tile_counter = c->w_tile_counters + (size_t)c->w_launch_parity * whitted::kTileHeads * whitted::kTileHeadStride;
+    p.tile_counter_next = c->w_tile_counters + (size_t)(1 - c->w_launch_parity) * whitted::kTileHeads * whitted::kTileHeadStride;
+    p.tiles_x = (width + 7) / 8;
+    p.tiles_y = (height + 7) / 8;
+    {
+        const uint64_t nt = (uint64_t)p.tiles_x * p.tiles_y;
+        auto gcd = [](uint64_t a, uint64_t b) { while (b) { const uint64_t t = a % b; a = b; b = t; } return a; };
+        uint64_t stride = (uint64_t)((double)nt * 0.6180339887498949);
+        if (stride < 1) stride = 1;
+        while (gcd(stride, nt) != 1) ++stride;   // (terminates: nt - 1 and 1 are coprime to nt)
+        p.tile_stride = (unsigned int)(stride % (nt > 1 ? nt : 2));
+        if (p.tile_stride == 0) p.tile_stride = 1;
+    }
     p.positions = c->w_positions;
     p.normals = c->w_normals;
     p.indices = c->w_indices;
@@ -981,9 +1025,18 @@ int rtgo_whitted_launch(rtgo_ctx* c, uint32_t width, uint32_t height, uint32_t s
     }
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    const unsigned int blocks = (unsigned int)(((uint64_t)width * height + whitted::kBlock - 1) / whitted::kBlock);
-    hipLaunchKernelGGL(whitted::render_kernel, dim3(blocks), dim3(whitted::kBlock), 0, c->stream, p);
+    // one persistent workgroup per CU; its LDS holds the walk's records when they fit beside the lanes' stacks
+    const size_t stack_bytes = (size_t)whitted::kRenderBlock * (size_t)p.stack_depth * sizeof(unsigned short);
+    const size_t rec_bytes = (size_t)p.n_recs * 4 * sizeof(float4);
+    const bool resident = rec_bytes + stack_bytes <= 160 * 1024;
+    const size_t lds = stack_bytes + (resident ? rec_bytes : 0);
+    const unsigned int n_tiles = p.tiles_x * p.tiles_y;
+    unsigned int blocks = (n_tiles + (whitted::kRenderBlock / 64) - 1) / (whitted::kRenderBlock / 64);
+    if (blocks > (unsigned int)c->num_cus) blocks = (unsigned int)c->num_cus;
+    if (resident) hipLaunchKernelGGL(whitted::render_kernel<true>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
+    else hipLaunchKernelGGL(whitted::render_kernel<false>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
     RTGO_HIP(c, hipGetLastError());
+    c->w_launch_parity = 1 - c->w_launch_parity;   // (only once the launch that zeroes the other head is in the stream)
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));
     c->ev_head = (c->ev_head + 1) % rtgo_ctx::kEvRing;
     c->ev_pending++;

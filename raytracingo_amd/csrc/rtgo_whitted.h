@@ -4,8 +4,11 @@
 // intersection and the acceleration structure to OptiX (built-in triangles, optixAccelBuild in sutil/Scene.cpp); here both are
 // written out: a Moeller-Trumbore test with a fixed operation order (shared with the oracle, so the two agree bit for bit) and
 // an LBVH over the triangles built on the device by one workgroup (Morton codes -> bitonic sort in LDS -> Karras hierarchy ->
-// bottom-up fit), kept in HBM / L2 and walked with a per-thread stack in LDS.  One thread per pixel, one launch per subframe:
-// a primary ray plus one shadow ray per point light, no recursion (whitted.cu traces none either).
+// bottom-up fit -> subtrees of at most four triangles collapsed into leaves, one 64-byte record per remaining node holding
+// BOTH children's boxes).  The render kernel is persistent like the analytic path's: one workgroup of 1024 threads per CU keeps
+// the records in LDS (when they fit: always below ~2000 triangles, usually up to the limit), its waves pull 8 x 8-pixel tiles
+// from a counter; one lane = one pixel, one launch per subframe: a primary ray plus one shadow ray per point light, no
+// recursion (whitted.cu traces none either).
 //
 // Compiled with -ffp-contract=off like the rest of the library: one IEEE rounding per operation.
 #pragma once
@@ -17,8 +20,12 @@ namespace whitted {
 
 constexpr int kMaxTriangles = 4096;   // one workgroup sorts the Morton keys in LDS (8 B per key)
 constexpr int kBuildThreads = 1024;
-constexpr int kStack = 32;            // per-thread traversal stack entries (LBVH depth is checked against it at build)
-constexpr int kBlock = 256;
+constexpr int kStack = 32;            // bound on the depth of the Karras hierarchy the build accepts (fit passes, parent chains)
+constexpr int kRenderBlock = 1024;    // one workgroup per CU shares one LDS copy of the records
+constexpr int kLeafTris = 4;          // a subtree of at most this many triangles is one leaf of the walk
+constexpr int kMaxWalkDepth = 40;
+constexpr int kTileHeads = 32;        // tile-queue heads (<= 64), kTileHeadStride words apart
+constexpr unsigned int kTileHeadStride = 16;     // per-lane stack entries (2 bytes each) the render kernel can be given
 
 struct PointLight {   // Light::Point, cuda/Light.h:47-53
     float color[3];
@@ -33,7 +40,15 @@ struct Pbr {          // MaterialData::Pbr without its texture handles, cuda/Mat
 };
 
 struct Params {       // whitted::LaunchParams, cuda/whitted.h:59-74
-    const float4* nodes;        // LBVH: 2 float4 per node, (bmin, left), (bmax, right); internal [0, n-2], leaves [n-1, 2n-2]: left = triangle, right = -1
+    const float4* recs;         // the walk's records, 4 float4 each: (left min, left link) (left max, -) (right min, right link) (right max, -);
+                                //   link >= 0: a record; link < 0: a leaf, -1 - (first sorted triangle | (count - 1) << 12)
+    const float4* tris;         // 3 float4 per triangle in Morton order: (P0, original index) (P1, -) (P2, -)
+    int n_recs;                 // 0: the whole mesh is one leaf (at most kLeafTris triangles)
+    int stack_depth;            // per-lane stack entries
+    unsigned int* tile_counter; // this launch's tile queue heads (kTileHeads of them, zero at launch) and the set it zeroes for the next launch
+    unsigned int* tile_counter_next;
+    unsigned int tiles_x, tiles_y;
+    unsigned int tile_stride;   // coprime to tiles_x * tiles_y
     const float* positions;     // 3 floats per vertex
     const float* normals;       // 3 floats per vertex, or null (then N = Ng, LocalGeometry.h:113-116)
     const unsigned int* indices;    // 3 per triangle
@@ -105,61 +120,97 @@ __device__ __forceinline__ bool node_hit(const float4 q0, const float4 q1, v3 o,
     return a <= b * 1.000002f + 1e-7f;
 }
 
-// closest hit (ANY = false: smallest t, lowest triangle index on ties) or any hit (ANY = true: the occlusion ray's
-// OPTIX_RAY_FLAG_TERMINATE_ON_FIRST_HIT, whitted.cu:140-151) over the triangle LBVH
+// the triangles [first, first + cnt) of one leaf, in Morton order (contiguous 48-byte records).  All of them are asked for before
+// the first one is tested: one round trip to L2 per leaf instead of one per triangle.
 template <bool ANY>
-__device__ __forceinline__ bool trace(const Params& p, unsigned int* __restrict__ s_stack, v3 o, v3 d, float tmin, float tmax, int& tri_out,
-                                      float& t_out, float& u_out, float& v_out)
+__device__ __forceinline__ bool leaf_tris(const float4* __restrict__ tris, int first, int cnt, v3 o, v3 d, float tmin, float tmax, int& best, int& best_pos,
+                                          float& bt, float& bu, float& bv)
 {
-    auto safe_inv = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : 1.0f / x; };
-    const v3 id = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-    int best = -1;
-    float bt = tmax, bu = 0.0f, bv = 0.0f;
-    int sp = 0;
-    int node = 0;
-    if (p.n_triangles == 1) node = 0;   // a single leaf at index n - 1 = 0
-    float tn;
-    {
-        const float4 q0 = p.nodes[0], q1 = p.nodes[1];
-        if (!node_hit(q0, q1, o, id, tmin, bt, tn)) return false;
+    float4 a[kLeafTris], b[kLeafTris], c[kLeafTris];
+#pragma unroll
+    for (int k = 0; k < kLeafTris; ++k) {
+        a[k] = b[k] = c[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (k < cnt) {   // (lanes whose leaf is shorter ask for nothing: the memory pipeline is paced by addresses, not by instructions)
+            a[k] = tris[3 * (first + k) + 0];
+            b[k] = tris[3 * (first + k) + 1];
+            c[k] = tris[3 * (first + k) + 2];
+        }
     }
-    for (;;) {
-        const float4 q0 = p.nodes[2 * node], q1 = p.nodes[2 * node + 1];
-        const int left = __float_as_int(q0.w), right = __float_as_int(q1.w);
-        bool popped = false;
-        if (right < 0) {
-            const unsigned int i0 = p.indices[3 * left + 0], i1 = p.indices[3 * left + 1], i2 = p.indices[3 * left + 2];
+#pragma unroll
+    for (int k = 0; k < kLeafTris; ++k) {
+        if (k < cnt) {
+            const int tri = __float_as_int(a[k].w);
             float t, u, v;
-            if (tri_intersect(ld3(p.positions, i0), ld3(p.positions, i1), ld3(p.positions, i2), o, d, tmin, tmax, t, u, v) &&
-                (t < bt || (t == bt && best >= 0 && left < best))) {
+            if (tri_intersect(mk(a[k].x, a[k].y, a[k].z), mk(b[k].x, b[k].y, b[k].z), mk(c[k].x, c[k].y, c[k].z), o, d, tmin, tmax, t, u, v) &&
+                (t < bt || (t == bt && best >= 0 && tri < best))) {
                 bt = t;
                 bu = u;
                 bv = v;
-                best = left;
-                if (ANY) break;
+                best = tri;
+                best_pos = first + k;
+                if (ANY) return true;
             }
-            popped = true;
-        } else {
-            const float4 l0 = p.nodes[2 * left], l1 = p.nodes[2 * left + 1];
-            const float4 h0 = p.nodes[2 * right], h1 = p.nodes[2 * right + 1];
-            float tl, tr;
-            const bool hl = node_hit(l0, l1, o, id, tmin, bt, tl);
-            const bool hr = node_hit(h0, h1, o, id, tmin, bt, tr);
-            const bool go_r = hr & (!hl | (tr < tl));
-            if (hl & hr) {
-                s_stack[sp * kBlock] = (unsigned int)(go_r ? left : right);
-                ++sp;
-            }
-            if (hl | hr) node = go_r ? right : left;
-            else popped = true;
         }
-        if (popped) {
-            if (sp == 0) break;
-            --sp;
-            node = (int)s_stack[sp * kBlock];
+    }
+    return false;
+}
+
+// closest hit (ANY = false: smallest t, lowest triangle index on ties) or any hit (ANY = true: the occlusion ray's
+// OPTIX_RAY_FLAG_TERMINATE_ON_FIRST_HIT, whitted.cu:140-151) over the triangle LBVH.  A step reads ONE record -- both
+// children's boxes, 64 contiguous bytes -- descends into the nearer child that is hit and parks the other one on the lane's
+// stack (2-byte entries: a record index, or 0x8000 | leaf code).
+template <bool ANY, typename Recs>
+__device__ __forceinline__ bool trace(const Params& p, Recs recs, unsigned short* __restrict__ s_stack, int stride, v3 o, v3 d, float tmin, float tmax,
+                                      int& tri_out, int& pos_out, float& t_out, float& u_out, float& v_out
+#ifdef RTGO_WHITTED_TIMING
+                                      , unsigned int& dbg_steps
+#endif
+)
+{
+    auto safe_inv = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : 1.0f / x; };
+    const v3 id = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    int best = -1, best_pos = 0;
+    float bt = tmax, bu = 0.0f, bv = 0.0f;
+    if (p.n_recs == 0) {
+        leaf_tris<ANY>(p.tris, 0, p.n_triangles, o, d, tmin, tmax, best, best_pos, bt, bu, bv);
+    } else {
+        int sp = 0;
+        int cur = 0;   // >= 0: a record; < 0: a leaf code
+        for (;;) {
+            bool pop = true;
+#ifdef RTGO_WHITTED_TIMING
+            dbg_steps += 1;
+#endif
+            if (cur >= 0) {
+                const float4 a0 = recs[4 * cur + 0], a1 = recs[4 * cur + 1], b0 = recs[4 * cur + 2], b1 = recs[4 * cur + 3];
+                float tl, tr;
+                const bool hl = node_hit(a0, a1, o, id, tmin, bt, tl);
+                const bool hr = node_hit(b0, b1, o, id, tmin, bt, tr);
+                const int ll = __float_as_int(a0.w), lr = __float_as_int(b0.w);
+                const bool go_r = hr && (!hl || tr < tl);
+                if (hl && hr) {
+                    const int far = go_r ? ll : lr;
+                    s_stack[sp * stride] = (unsigned short)(far >= 0 ? far : (0x8000 | (-1 - far)));
+                    ++sp;
+                }
+                if (hl || hr) {
+                    cur = go_r ? lr : ll;
+                    pop = false;
+                }
+            } else {
+                const int code = -1 - cur;
+                if (leaf_tris<ANY>(p.tris, code & 0xFFF, (code >> 12) + 1, o, d, tmin, tmax, best, best_pos, bt, bu, bv)) break;   // (true only when ANY)
+            }
+            if (pop) {
+                if (sp == 0) break;
+                --sp;
+                const int e = (int)s_stack[sp * stride];
+                cur = (e & 0x8000) ? -1 - (e & 0x7FFF) : e;
+            }
         }
     }
     tri_out = best;
+    pos_out = best_pos;
     t_out = bt;
     u_out = bu;
     v_out = bv;
@@ -187,96 +238,185 @@ __device__ __forceinline__ float ggx_normal(float NdotH, float alpha)
     return a2 / (kPi * x * x);
 }
 
-__global__ __launch_bounds__(kBlock) void render_kernel(const Params p)
+template <bool RESIDENT>
+__global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
 {
-    __shared__ unsigned int s_stack_all[kStack * kBlock];
-    unsigned int* s_stack = s_stack_all + threadIdx.x;
-    const unsigned int idx = blockIdx.x * kBlock + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w_smem[];
+#ifdef RTGO_WHITTED_TIMING
+    const unsigned long long wt0 = wall_clock64();
+    unsigned long long wt_tiles = 0, wt_n = 0, wt_max = 0;
+    unsigned int wt_stepmax = 0;
+#endif
+    float4* s_recs = reinterpret_cast<float4*>(w_smem);
+    const int stride = (int)blockDim.x;
+    unsigned short* s_stack = reinterpret_cast<unsigned short*>(s_recs + (RESIDENT ? 4 * p.n_recs : 0)) + threadIdx.x;   // entry e at [e * stride]
+    if (RESIDENT) {
+        for (int i = (int)threadIdx.x; i < 4 * p.n_recs; i += stride) s_recs[i] = p.recs[i];
+        __syncthreads();
+    }
+#ifdef RTGO_WHITTED_TIMING
+    const unsigned long long wt1 = wall_clock64();
+#endif
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned int)kTileHeads) p.tile_counter_next[kTileHeadStride * threadIdx.x] = 0u;
+    auto pick = [&]() {
+        if constexpr (RESIDENT) return static_cast<const float4*>(s_recs);
+        else return p.recs;
+    };
+    const auto recs = pick();
+    const unsigned int lane = threadIdx.x & 63u;
+    const unsigned int n_tiles = p.tiles_x * p.tiles_y;
     unsigned int rays = 0, occl = 0;
-    if (idx < p.width * p.height) {
-        const unsigned int y = idx / p.width, x = idx - y * p.width;
-        // __raygen__pinhole, whitted.cu:183-240
-        unsigned int seed = tea4(y * p.width + x, p.subframe);
-        float jx = 0.0f, jy = 0.0f;
-        if (p.subframe != 0) {
-            jx = rnd(seed) - 0.5f;   // x first (source order)
-            jy = rnd(seed) - 0.5f;
+    // Tile queue: kTileHeads counters 64 bytes apart, head h serves the tiles h, h + kTileHeads, ...  (one counter hands out ~88
+    // entries per microsecond chip-wide: a 1080p subframe is 32 k tiles).  A wave starts on head blockIdx % kTileHeads; when that is
+    // dry it looks at all heads with one load and moves to an open one.  The pull for the next tile is in flight while the
+    // current one is rendered.
+    auto tiles_of = [&](unsigned int h) { return (n_tiles + (unsigned int)kTileHeads - 1u - h) / (unsigned int)kTileHeads; };
+    unsigned int head = blockIdx.x % (unsigned int)kTileHeads;
+    unsigned int pending = 0u;
+    if (lane == 0u) pending = atomicAdd(p.tile_counter + kTileHeadStride * head, 1u);
+    for (;;) {
+        unsigned int pos = (unsigned int)__builtin_amdgcn_readfirstlane((int)pending);
+        if (pos >= tiles_of(head)) {
+            // this head is dry: any other one still open?
+            unsigned int v = 0xFFFFFFFFu;
+            if (lane < (unsigned int)kTileHeads) v = __hip_atomic_load(p.tile_counter + kTileHeadStride * lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long open = __builtin_amdgcn_ballot_w64(lane < (unsigned int)kTileHeads && v < tiles_of(lane));
+            if (open == 0ull) break;
+            // the first open head after this one (waves spread over the open heads instead of all falling on the lowest)
+            const unsigned long long above = open & ~((2ull << head) - 1ull);
+            head = (unsigned int)(__ffsll((long long)(above ? above : open)) - 1);
+            if (lane == 0u) pending = atomicAdd(p.tile_counter + kTileHeadStride * head, 1u);
+            continue;
         }
-        const float dx = 2.0f * (((float)x + jx) / (float)p.width) - 1.0f;
-        const float dy = 2.0f * (((float)y + jy) / (float)p.height) - 1.0f;
-        const v3 rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.W));
-        const v3 ro = p.eye;
-        v3 result = p.miss;   // __miss__constant_radiance, :243-246
-        int tri;
-        float t, bu, bv;
-        rays += 1;
-        if (trace<false>(p, s_stack, ro, rd, 0.01f, 1e16f, tri, t, bu, bv)) {
-            // __closesthit__radiance, :255-337, with getLocalGeometry (LocalGeometry.h:55-141) for a mesh in world space
-            const unsigned int i0 = p.indices[3 * tri + 0], i1 = p.indices[3 * tri + 1], i2 = p.indices[3 * tri + 2];
-            const v3 P0 = ld3(p.positions, i0), P1 = ld3(p.positions, i1), P2 = ld3(p.positions, i2);
-            const float w0 = 1.0f - bu - bv;
-            const v3 P = vadd(vadd(vscale(P0, w0), vscale(P1, bu)), vscale(P2, bv));
-            const v3 Ng = vnormalize(vcross(vsub(P1, P0), vsub(P2, P0)));
-            v3 N = Ng;
-            if (p.normals) {
-                const v3 N0 = ld3(p.normals, i0), N1 = ld3(p.normals, i1), N2 = ld3(p.normals, i2);
-                N = vnormalize(vadd(vadd(vscale(N0, w0), vscale(N1, bu)), vscale(N2, bv)));
+        // queue entry -> tile through a fixed permutation (multiplication by a number coprime to the tile count, near the golden
+        // section of it): in row-major order every wave of the chip reaches the dense part of the mesh at the same time and they all
+        // queue at the vector memory pipeline for its triangles; scattered, tiles that wait for triangles overlap tiles that do not
+        const unsigned int tile = (unsigned int)(((unsigned long long)(pos * (unsigned int)kTileHeads + head) * p.tile_stride) % n_tiles);
+        if (lane == 0u) pending = atomicAdd(p.tile_counter + kTileHeadStride * head, 1u);
+#ifdef RTGO_WHITTED_TIMING
+        const unsigned long long wt2 = wall_clock64();
+        wt_n += 1;
+        unsigned int wt_steps = 0;
+#endif
+        const unsigned int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
+        const unsigned int x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+        if (x < p.width && y < p.height) {
+            const unsigned int idx = y * p.width + x;
+            // __raygen__pinhole, whitted.cu:183-240
+            unsigned int seed = tea4(y * p.width + x, p.subframe);
+            float jx = 0.0f, jy = 0.0f;
+            if (p.subframe != 0) {
+                jx = rnd(seed) - 0.5f;   // x first (source order)
+                jy = rnd(seed) - 0.5f;
             }
-            const Pbr m = p.materials[p.tri_material ? p.tri_material[tri] : 0u];
-            const v3 base = mk(m.base_color[0], m.base_color[1], m.base_color[2]);
-            const float metallic = m.metallic * 1.0f, roughness = m.roughness * 1.0f;   // (x the (1,1,1,1) of an absent texture, :270-275)
-            const float F0 = 0.04f;
-            const v3 diff_color = vscale(vscale(base, 1.0f - F0), 1.0f - metallic);
-            // lerp(a, b, t) = a + t * (b - a), vec_math.h:496-499
-            const v3 spec_color = vadd(mk(F0, F0, F0), vscale(vsub(base, mk(F0, F0, F0)), metallic));
-            const float alpha = roughness * roughness;
-            result = mk(0.0f, 0.0f, 0.0f);
-            for (int l = 0; l < p.n_lights; ++l) {
-                const PointLight L = p.lights[l];
-                const v3 toL = vsub(mk(L.position[0], L.position[1], L.position[2]), P);
-                const float Ldist = vlength(toL);
-                const v3 Lv = vscale(toL, 1.0f / Ldist);   // float3 / float multiplies by the reciprocal (vec_math.h:479-483)
-                const v3 Vv = vneg(vnormalize(rd));
-                const v3 H = vnormalize(vadd(Lv, Vv));
-                const float NdotL = vdot(N, Lv), NdotV = vdot(N, Vv), NdotH = vdot(N, H), VdotH = vdot(Vv, H);
-                if (NdotL > 0.0f && NdotV > 0.0f) {
-                    int ot;
-                    float tt, uu, vv;
-                    rays += 1;
-                    occl += 1;
-                    if (!trace<true>(p, s_stack, P, Lv, 0.001f, Ldist - 0.001f, ot, tt, uu, vv)) {
-                        const v3 F = schlick(spec_color, VdotH);
-                        const float G = vis(NdotL, NdotV, alpha);
-                        const float D = ggx_normal(NdotH, alpha);
-                        const v3 one_minus_F = vsub(mk(1.0f, 1.0f, 1.0f), F);
-                        const v3 dd = vmul(one_minus_F, diff_color);
-                        const float ip = 1.0f / kPi;
-                        const v3 diff = vscale(dd, ip);   // float3 / float
-                        const v3 spec = vscale(vscale(F, G), D);
-                        const v3 lc = vscale(mk(L.color[0], L.color[1], L.color[2]), L.intensity);
-                        result = vadd(result, vmul(vscale(lc, NdotL), vadd(diff, spec)));
+            const float dx = 2.0f * (((float)x + jx) / (float)p.width) - 1.0f;
+            const float dy = 2.0f * (((float)y + jy) / (float)p.height) - 1.0f;
+            const v3 rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.W));
+            const v3 ro = p.eye;
+            v3 result = p.miss;   // __miss__constant_radiance, :243-246
+            int tri, tpos;
+            float t, bu, bv;
+            rays += 1;
+            if (trace<false>(p, recs, s_stack, stride, ro, rd, 0.01f, 1e16f, tri, tpos, t, bu, bv
+#ifdef RTGO_WHITTED_TIMING
+                             , wt_steps
+#endif
+                             )) {
+                // __closesthit__radiance, :255-337, with getLocalGeometry (LocalGeometry.h:55-141) for a mesh in world space.
+                // (the corners come from the Morton-ordered copy the walk read them from: same values, no trip through the index array)
+                const float4 c0 = p.tris[3 * tpos + 0], c1 = p.tris[3 * tpos + 1], c2 = p.tris[3 * tpos + 2];
+                const v3 P0 = mk(c0.x, c0.y, c0.z), P1 = mk(c1.x, c1.y, c1.z), P2 = mk(c2.x, c2.y, c2.z);
+                const float w0 = 1.0f - bu - bv;
+                const v3 P = vadd(vadd(vscale(P0, w0), vscale(P1, bu)), vscale(P2, bv));
+                const v3 Ng = vnormalize(vcross(vsub(P1, P0), vsub(P2, P0)));
+                v3 N = Ng;
+                if (p.normals) {
+                    const unsigned int i0 = p.indices[3 * tri + 0], i1 = p.indices[3 * tri + 1], i2 = p.indices[3 * tri + 2];
+                    const v3 N0 = ld3(p.normals, i0), N1 = ld3(p.normals, i1), N2 = ld3(p.normals, i2);
+                    N = vnormalize(vadd(vadd(vscale(N0, w0), vscale(N1, bu)), vscale(N2, bv)));
+                }
+                const Pbr m = p.materials[p.tri_material ? p.tri_material[tri] : 0u];
+                const v3 base = mk(m.base_color[0], m.base_color[1], m.base_color[2]);
+                const float metallic = m.metallic * 1.0f, roughness = m.roughness * 1.0f;   // (x the (1,1,1,1) of an absent texture, :270-275)
+                const float F0 = 0.04f;
+                const v3 diff_color = vscale(vscale(base, 1.0f - F0), 1.0f - metallic);
+                // lerp(a, b, t) = a + t * (b - a), vec_math.h:496-499
+                const v3 spec_color = vadd(mk(F0, F0, F0), vscale(vsub(base, mk(F0, F0, F0)), metallic));
+                const float alpha = roughness * roughness;
+                result = mk(0.0f, 0.0f, 0.0f);
+                for (int l = 0; l < p.n_lights; ++l) {
+                    const PointLight L = p.lights[l];
+                    const v3 toL = vsub(mk(L.position[0], L.position[1], L.position[2]), P);
+                    const float Ldist = vlength(toL);
+                    const v3 Lv = vscale(toL, 1.0f / Ldist);   // float3 / float multiplies by the reciprocal (vec_math.h:479-483)
+                    const v3 Vv = vneg(vnormalize(rd));
+                    const v3 H = vnormalize(vadd(Lv, Vv));
+                    const float NdotL = vdot(N, Lv), NdotV = vdot(N, Vv), NdotH = vdot(N, H), VdotH = vdot(Vv, H);
+                    if (NdotL > 0.0f && NdotV > 0.0f) {
+                        int ot, opos;
+                        float tt, uu, vv;
+                        rays += 1;
+                        occl += 1;
+                        if (!trace<true>(p, recs, s_stack, stride, P, Lv, 0.001f, Ldist - 0.001f, ot, opos, tt, uu, vv
+#ifdef RTGO_WHITTED_TIMING
+                                         , wt_steps
+#endif
+                                         )) {
+                            const v3 F = schlick(spec_color, VdotH);
+                            const float G = vis(NdotL, NdotV, alpha);
+                            const float D = ggx_normal(NdotH, alpha);
+                            const v3 one_minus_F = vsub(mk(1.0f, 1.0f, 1.0f), F);
+                            const v3 dd = vmul(one_minus_F, diff_color);
+                            const float ip = 1.0f / kPi;
+                            const v3 diff = vscale(dd, ip);   // float3 / float
+                            const v3 spec = vscale(vscale(F, G), D);
+                            const v3 lc = vscale(mk(L.color[0], L.color[1], L.color[2]), L.intensity);
+                            result = vadd(result, vmul(vscale(lc, NdotL), vadd(diff, spec)));
+                        }
                     }
                 }
             }
+            // whitted.cu:226-239
+            v3 acc = result;
+            if (p.subframe > 0) {
+                const float a = 1.0f / (float)(p.subframe + 1);
+                const float4 prev = p.accum[idx];
+                acc = vadd(mk(prev.x, prev.y, prev.z), vscale(vsub(acc, mk(prev.x, prev.y, prev.z)), a));
+            }
+            p.accum[idx] = make_float4(acc.x, acc.y, acc.z, 1.0f);
+            // make_color, whitted.cu:164-173: gamma 2.2
+            const float g = (float)(1.0 / 2.2f);
+            p.image[idx] = make_uchar4((unsigned char)(powf(clampf(acc.x, 0.0f, 1.0f), g) * 255.0f), (unsigned char)(powf(clampf(acc.y, 0.0f, 1.0f), g) * 255.0f),
+                                       (unsigned char)(powf(clampf(acc.z, 0.0f, 1.0f), g) * 255.0f), 255u);
         }
-        // whitted.cu:226-239
-        v3 acc = result;
-        if (p.subframe > 0) {
-            const float a = 1.0f / (float)(p.subframe + 1);
-            const float4 prev = p.accum[idx];
-            acc = vadd(mk(prev.x, prev.y, prev.z), vscale(vsub(acc, mk(prev.x, prev.y, prev.z)), a));
+#ifdef RTGO_WHITTED_TIMING
+        {
+            unsigned int mx = wt_steps;
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned int o2 = (unsigned int)__shfl_xor((int)mx, off, 64);
+                mx = o2 > mx ? o2 : mx;
+            }
+            wt_stepmax = mx > wt_stepmax ? mx : wt_stepmax;
         }
-        p.accum[idx] = make_float4(acc.x, acc.y, acc.z, 1.0f);
-        // make_color, whitted.cu:164-173: gamma 2.2
-        const float g = (float)(1.0 / 2.2f);
-        p.image[idx] = make_uchar4((unsigned char)(powf(clampf(acc.x, 0.0f, 1.0f), g) * 255.0f), (unsigned char)(powf(clampf(acc.y, 0.0f, 1.0f), g) * 255.0f),
-                                   (unsigned char)(powf(clampf(acc.z, 0.0f, 1.0f), g) * 255.0f), 255u);
+        const unsigned long long wt3 = wall_clock64() + (rays == 0xFFFFFFFFu ? 1 : 0) - wt2;
+        wt_tiles += wt3;
+        if (x < p.width && y < p.height) p.accum[y * p.width + x].w = (float)wt3 + 0.001f * (float)wt_steps;   // (diagnostic: ticks of the tile . steps of the pixel)
+        wt_max = wt3 > wt_max ? wt3 : wt_max;
+#endif
     }
     rays = wave_sum(rays);
     occl = wave_sum(occl);
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0u) {
         atomicAdd(&p.counters[0], (unsigned long long)rays);
         atomicAdd(&p.counters[1], (unsigned long long)occl);
+#ifdef RTGO_WHITTED_TIMING
+        // diagnostic build (tools/whitted_perf.py prints them): 10 ns ticks summed over the waves
+        atomicAdd(&p.counters[2], wall_clock64() - wt0);   // wave lifetime          -> rtgo_stats.node_visits
+        atomicMax(&p.counters[3], (unsigned long long)wt_stepmax);   // most walk steps of one pixel (its three rays) -> prim_tests
+        atomicAdd(&p.counters[4], wt_tiles);               // inside tiles           -> hits
+        atomicAdd(&p.counters[5], wt_n);                   // tiles                  -> dbg_fast_boxes
+        atomicMax(&p.counters[6], wt_max);                 // the longest tile       -> dbg_fast_tests
+#endif
     }
 }
 
@@ -285,17 +425,22 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const Params p)
 // buildMeshAccels).  Same recipe as the analytic path's canonical tree: 30-bit Morton code of the centroid normalised to the
 // scene bounds, stable order by (code, triangle index), Karras 2012, one triangle per leaf, bottom-up fit.
 // Boxes are padded by 1e-4 of the scene's extent + 1e-6: the slab test rounds, the triangle test must never be cut off.
-// out_meta = {depth}.
+// out_meta = {depth of the hierarchy, records of the walk, stack entries the walk needs}.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __restrict__ positions, const unsigned int* __restrict__ indices, int n,
                                                               float4* __restrict__ nodes, int* __restrict__ parent, int* __restrict__ visit,
-                                                              int* __restrict__ out_meta)
+                                                              int* __restrict__ first_of, int* __restrict__ count_of, int* __restrict__ rec_of,
+                                                              float4* __restrict__ recs, float4* __restrict__ tris, int* __restrict__ out_meta)
 {
     __shared__ unsigned long long s_keys[kMaxTriangles];
     __shared__ float s_red[6][kBuildThreads];
-    __shared__ int s_depth;
+    __shared__ int s_depth, s_nrec, s_wdepth;
     const int tid = threadIdx.x;
-    if (tid == 0) s_depth = 0;
+    if (tid == 0) {
+        s_depth = 0;
+        s_nrec = 1;     // record 0 is the root's
+        s_wdepth = 0;
+    }
     // scene bounds
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = tid; i < n; i += kBuildThreads)
@@ -404,6 +549,8 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
         nodes[2 * i + 1].w = __int_as_float(right);
         parent[left] = i;
         parent[right] = i;
+        first_of[i] = lo_i;               // the node's triangles: sorted positions [lo_i, hi_i]
+        count_of[i] = hi_i - lo_i + 1;
     }
     __syncthreads();
     // bottom-up fit, level by level: a node is fitted in the pass after both of its children (visit[] = 1 once a node is done;
@@ -434,7 +581,42 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
         atomicMax(&s_depth, dd);
     }
     __syncthreads();
-    if (tid == 0) out_meta[0] = s_depth;
+    // ---- the structure the render kernel walks --------------------------------------------------------------------
+    // Subtrees of at most kLeafTris triangles become leaves (their triangles are neighbours in Morton order); every node above
+    // them gets one record with BOTH children's boxes, so that a step of the walk reads 64 contiguous bytes.
+    for (int i = tid; i < n - 1; i += kBuildThreads) rec_of[i] = count_of[i] > kLeafTris ? (i == 0 ? 0 : atomicAdd(&s_nrec, 1)) : -1;
+    __syncthreads();
+    auto link_of = [&](int child) -> int {
+        if (child >= leaf0) return -1 - (child - leaf0);                                         // one triangle
+        if (count_of[child] <= kLeafTris) return -1 - (first_of[child] | ((count_of[child] - 1) << 12));
+        return rec_of[child];
+    };
+    for (int i = tid; i < n - 1; i += kBuildThreads) {
+        const int r = rec_of[i];
+        if (r < 0) continue;
+        const int L = __float_as_int(nodes[2 * i + 0].w), R = __float_as_int(nodes[2 * i + 1].w);
+        const float4 a0 = nodes[2 * L], a1 = nodes[2 * L + 1], b0 = nodes[2 * R], b1 = nodes[2 * R + 1];
+        recs[4 * r + 0] = make_float4(a0.x, a0.y, a0.z, __int_as_float(link_of(L)));
+        recs[4 * r + 1] = make_float4(a1.x, a1.y, a1.z, 0.0f);
+        recs[4 * r + 2] = make_float4(b0.x, b0.y, b0.z, __int_as_float(link_of(R)));
+        recs[4 * r + 3] = make_float4(b1.x, b1.y, b1.z, 0.0f);
+        int dd = 1;   // stack entries a walk can hold below this record: one per record on the way down, its own included
+        for (int q = parent[i]; q >= 0; q = parent[q]) ++dd;
+        atomicMax(&s_wdepth, dd);
+    }
+    for (int i = tid; i < n; i += kBuildThreads) {
+        const unsigned int tri = (unsigned int)(s_keys[i] & 0xFFFFFFFFu);
+        const unsigned int i0 = indices[3 * tri + 0], i1 = indices[3 * tri + 1], i2 = indices[3 * tri + 2];
+        tris[3 * i + 0] = make_float4(positions[3 * i0 + 0], positions[3 * i0 + 1], positions[3 * i0 + 2], __int_as_float((int)tri));
+        tris[3 * i + 1] = make_float4(positions[3 * i1 + 0], positions[3 * i1 + 1], positions[3 * i1 + 2], 0.0f);
+        tris[3 * i + 2] = make_float4(positions[3 * i2 + 0], positions[3 * i2 + 1], positions[3 * i2 + 2], 0.0f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        out_meta[0] = s_depth;
+        out_meta[1] = n > kLeafTris ? s_nrec : 0;   // 0: the mesh is one leaf, no records
+        out_meta[2] = s_wdepth;
+    }
 }
 
 }  // namespace whitted
