@@ -101,6 +101,10 @@ struct rtgo_ctx {
     float4* w_nodes = nullptr;
     float4* w_recs = nullptr;              // the walk's records (4 float4 each) and the triangles in Morton order (3 float4 each)
     float4* w_tris = nullptr;
+    uint4* w_qrecs = nullptr;              // the compact form: quantised records, (vertex indices | triangle index) per triangle
+    uint2* w_tidx = nullptr;
+    int w_n_vertices = 0;
+    v3 w_grid_lo{0, 0, 0}, w_grid_step{0, 0, 0};
     int* w_scratch = nullptr;
     unsigned int* w_tile_counters = nullptr;   // two sets of tile-queue heads: a launch counts on one and zeroes the other
     int w_n_recs = 0, w_walk_depth = 0, w_launch_parity = 0;
@@ -319,8 +323,9 @@ int rtgo_create(int device, rtgo_ctx** out)
         if (err == hipSuccess) err = hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     // (the build kernel holds ~58 KB of static LDS; its dynamic part is the fast walk's tree under construction)
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildDynLds);
-    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kAllInL2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kRecordsInLds>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kAllInLds>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess) err = hipDeviceSynchronize();  // the null-stream memsets above must land before any launch
     if (err != hipSuccess) {
         std::string m = std::string("rtgo_create: ") + hipGetErrorString(err);
@@ -363,6 +368,8 @@ int rtgo_destroy(rtgo_ctx* c)
     (void)hipFree(c->w_nodes);
     (void)hipFree(c->w_recs);
     (void)hipFree(c->w_tris);
+    (void)hipFree(c->w_qrecs);
+    (void)hipFree(c->w_tidx);
     (void)hipFree(c->w_scratch);
     for (int i = 0; i < rtgo_ctx::kEvRing; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
@@ -894,12 +901,16 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     (void)hipFree(c->w_nodes);
     (void)hipFree(c->w_recs);
     (void)hipFree(c->w_tris);
+    (void)hipFree(c->w_qrecs);
+    (void)hipFree(c->w_tidx);
     (void)hipFree(c->w_scratch);
     c->w_positions = c->w_normals = nullptr;
     c->w_indices = c->w_tri_material = nullptr;
     c->w_materials = nullptr;
     c->w_nodes = nullptr;
     c->w_recs = c->w_tris = nullptr;
+    c->w_qrecs = nullptr;
+    c->w_tidx = nullptr;
     c->w_scratch = nullptr;
     c->w_triangles = 0;
     const size_t vb = (size_t)n_vertices * 3 * sizeof(float), ib = (size_t)n_triangles * 3 * sizeof(unsigned int);
@@ -920,7 +931,9 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     RTGO_HIP(c, hipMalloc(&c->w_nodes, (size_t)(2 * n_triangles - 1) * 2 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->w_recs, (size_t)n_triangles * 4 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->w_tris, (size_t)n_triangles * 3 * sizeof(float4)));
-    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(6 * n_triangles + 8) * sizeof(int)));   // parent [2n-1], visit, first, count, record [n each], meta
+    RTGO_HIP(c, hipMalloc(&c->w_qrecs, (size_t)n_triangles * 2 * sizeof(uint4)));
+    RTGO_HIP(c, hipMalloc(&c->w_tidx, (size_t)n_triangles * sizeof(uint2)));
+    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(6 * n_triangles + 16) * sizeof(int)));   // parent [2n-1], visit, first, count, record [n each], meta
     int* parent = c->w_scratch;
     int* visit = parent + (2 * n_triangles - 1);
     int* first_of = visit + n_triangles;
@@ -928,9 +941,9 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     int* rec_of = count_of + n_triangles;
     int* meta = rec_of + n_triangles;
     hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), 0, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
-                       parent, visit, first_of, count_of, rec_of, c->w_recs, c->w_tris, meta);
+                       parent, visit, first_of, count_of, rec_of, c->w_recs, c->w_tris, c->w_qrecs, c->w_tidx, meta);
     RTGO_HIP(c, hipGetLastError());
-    int m[3] = {0, 0, 0};
+    int m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(m, meta, sizeof m, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     if (m[0] > whitted::kStack)
@@ -940,6 +953,9 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_whitted_set_mesh: the walk needs " + std::to_string(m[2]) + " stack entries (limit " +
                                                std::to_string(whitted::kMaxWalkDepth) + ")");
     c->w_n_recs = m[1];
+    c->w_n_vertices = (int)n_vertices;
+    std::memcpy(&c->w_grid_lo, &m[3], 3 * sizeof(float));
+    std::memcpy(&c->w_grid_step, &m[6], 3 * sizeof(float));
     c->w_walk_depth = m[2] < 1 ? 1 : m[2];
     if (!c->w_tile_counters) {
         const size_t heads_bytes = 2 * (size_t)whitted::kTileHeads * whitted::kTileHeadStride * sizeof(unsigned int);
@@ -986,6 +1002,11 @@ int rtgo_whitted_launch(rtgo_ctx* c, uint32_t width, uint32_t height, uint32_t s
     p.recs = c->w_recs;
     p.tris = c->w_tris;
     p.n_recs = c->w_n_recs;
+    p.qrecs = c->w_qrecs;
+    p.tidx = c->w_tidx;
+    p.n_vertices = c->w_n_vertices;
+    p.grid_lo = c->w_grid_lo;
+    p.grid_step = c->w_grid_step;
     p.stack_depth = c->w_walk_depth;
     p.tile_counter = c->w_tile_counters + (size_t)c->w_launch_parity * whitted::kTileHeads * whitted::kTileHeadStride;
     p.tile_counter_next = c->w_tile_counters + (size_t)(1 - c->w_launch_parity) * whitted::kTileHeads * whitted::kTileHeadStride;
@@ -1025,16 +1046,23 @@ int rtgo_whitted_launch(rtgo_ctx* c, uint32_t width, uint32_t height, uint32_t s
     }
     const int slot = c->ev_head;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    // one persistent workgroup per CU; its LDS holds the walk's records when they fit beside the lanes' stacks
+    // one persistent workgroup per CU.  Its LDS holds, beside the lanes' stacks, as much of the structure as fits: everything in
+    // its compact form (quantised records, vertices, 16-bit vertex indices), or the fp32 records alone, or nothing
     const size_t stack_bytes = (size_t)whitted::kRenderBlock * (size_t)p.stack_depth * sizeof(unsigned short);
     const size_t rec_bytes = (size_t)p.n_recs * 4 * sizeof(float4);
-    const bool resident = rec_bytes + stack_bytes <= 160 * 1024;
-    const size_t lds = stack_bytes + (resident ? rec_bytes : 0);
+    const size_t compact_bytes = (size_t)p.n_recs * 2 * sizeof(uint4) + (size_t)p.n_vertices * sizeof(float4) + (size_t)p.n_triangles * sizeof(uint2);
+    const size_t lds_cap = 160 * 1024;
+    const int mode_cap = (int)env_uint("RTGO_WHITTED_MODE", (unsigned int)whitted::kAllInLds);   // (test and experiment knob: 0 / 1 / 2 = at most that much in LDS)
+    int mode = whitted::kAllInL2;
+    if (mode_cap >= whitted::kAllInLds && p.n_vertices <= 65535 && compact_bytes + stack_bytes <= lds_cap) mode = whitted::kAllInLds;
+    else if (mode_cap >= whitted::kRecordsInLds && rec_bytes + stack_bytes <= lds_cap) mode = whitted::kRecordsInLds;
+    const size_t lds = stack_bytes + (mode == whitted::kAllInLds ? compact_bytes : (mode == whitted::kRecordsInLds ? rec_bytes : 0));
     const unsigned int n_tiles = p.tiles_x * p.tiles_y;
     unsigned int blocks = (n_tiles + (whitted::kRenderBlock / 64) - 1) / (whitted::kRenderBlock / 64);
     if (blocks > (unsigned int)c->num_cus) blocks = (unsigned int)c->num_cus;
-    if (resident) hipLaunchKernelGGL(whitted::render_kernel<true>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
-    else hipLaunchKernelGGL(whitted::render_kernel<false>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
+    if (mode == whitted::kAllInLds) hipLaunchKernelGGL(whitted::render_kernel<whitted::kAllInLds>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
+    else if (mode == whitted::kRecordsInLds) hipLaunchKernelGGL(whitted::render_kernel<whitted::kRecordsInLds>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
+    else hipLaunchKernelGGL(whitted::render_kernel<whitted::kAllInL2>, dim3(blocks), dim3(whitted::kRenderBlock), lds, c->stream, p);
     RTGO_HIP(c, hipGetLastError());
     c->w_launch_parity = 1 - c->w_launch_parity;   // (only once the launch that zeroes the other head is in the stream)
     RTGO_HIP(c, hipEventRecord(c->ev_stop[slot], c->stream));

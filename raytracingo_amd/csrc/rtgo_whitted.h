@@ -24,6 +24,9 @@ constexpr int kStack = 32;            // bound on the depth of the Karras hierar
 constexpr int kRenderBlock = 1024;    // one workgroup per CU shares one LDS copy of the records
 constexpr int kLeafTris = 4;          // a subtree of at most this many triangles is one leaf of the walk
 constexpr int kMaxWalkDepth = 40;
+// where the walk reads from: records and triangles in L2 / fp32 records in LDS, triangles in L2 / quantised records, vertices and
+// triangle indices all in LDS
+constexpr int kAllInL2 = 0, kRecordsInLds = 1, kAllInLds = 2;
 constexpr int kTileHeads = 32;        // tile-queue heads (<= 64), kTileHeadStride words apart
 constexpr unsigned int kTileHeadStride = 16;     // per-lane stack entries (2 bytes each) the render kernel can be given
 
@@ -43,6 +46,11 @@ struct Params {       // whitted::LaunchParams, cuda/whitted.h:59-74
     const float4* recs;         // the walk's records, 4 float4 each: (left min, left link) (left max, -) (right min, right link) (right max, -);
                                 //   link >= 0: a record; link < 0: a leaf, -1 - (first sorted triangle | (count - 1) << 12)
     const float4* tris;         // 3 float4 per triangle in Morton order: (P0, original index) (P1, -) (P2, -)
+    // the compact form of the same structure, for meshes that fit a CU's LDS whole (kAllInLds):
+    const uint4* qrecs;         // 2 uint4 per record: (x, y, z planes of the left box as lo | hi << 16 on a 16-bit grid, left link), same for the right box
+    const uint2* tidx;          // per triangle in Morton order: (v0 | v1 << 16, v2 | original index << 16)
+    int n_vertices;
+    v3 grid_lo, grid_step;      // world = grid_lo + cell * grid_step
     int n_recs;                 // 0: the whole mesh is one leaf (at most kLeafTris triangles)
     int stack_depth;            // per-lane stack entries
     unsigned int* tile_counter; // this launch's tile queue heads (kTileHeads of them, zero at launch) and the set it zeroes for the next launch
@@ -161,11 +169,7 @@ __device__ __forceinline__ bool leaf_tris(const float4* __restrict__ tris, int f
 // stack (2-byte entries: a record index, or 0x8000 | leaf code).
 template <bool ANY, typename Recs>
 __device__ __forceinline__ bool trace(const Params& p, Recs recs, unsigned short* __restrict__ s_stack, int stride, v3 o, v3 d, float tmin, float tmax,
-                                      int& tri_out, int& pos_out, float& t_out, float& u_out, float& v_out
-#ifdef RTGO_WHITTED_TIMING
-                                      , unsigned int& dbg_steps
-#endif
-)
+                                      int& tri_out, int& pos_out, float& t_out, float& u_out, float& v_out)
 {
     auto safe_inv = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : 1.0f / x; };
     const v3 id = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
@@ -178,9 +182,6 @@ __device__ __forceinline__ bool trace(const Params& p, Recs recs, unsigned short
         int cur = 0;   // >= 0: a record; < 0: a leaf code
         for (;;) {
             bool pop = true;
-#ifdef RTGO_WHITTED_TIMING
-            dbg_steps += 1;
-#endif
             if (cur >= 0) {
                 const float4 a0 = recs[4 * cur + 0], a1 = recs[4 * cur + 1], b0 = recs[4 * cur + 2], b1 = recs[4 * cur + 3];
                 float tl, tr;
@@ -238,20 +239,143 @@ __device__ __forceinline__ float ggx_normal(float NdotH, float alpha)
     return a2 / (kPi * x * x);
 }
 
-template <bool RESIDENT>
+// ---- the walk over the LDS-resident compact form (kAllInLds) -------------------------------------------------------------
+// slab test of a quantised box: world plane = grid_lo + cell * step, so t = fma(cell, step / d, (grid_lo - o) / d) -- one FMA per
+// plane on two per-ray constants.  The build rounds lower planes down and upper planes up by one extra cell (3e-5 of the scene), which
+// swallows the rounding of these products: the boxes only grow.
+__device__ __forceinline__ bool qbox_hit(const uint4 q, v3 sid, v3 snoid, float tmin, float tmax, float& tn)
+{
+    float t0 = fmaf((float)(q.x & 0xFFFFu), sid.x, snoid.x), t1 = fmaf((float)(q.x >> 16), sid.x, snoid.x);
+    float a = fminf(t0, t1), b = fmaxf(t0, t1);
+    t0 = fmaf((float)(q.y & 0xFFFFu), sid.y, snoid.y);
+    t1 = fmaf((float)(q.y >> 16), sid.y, snoid.y);
+    a = fmaxf(a, fminf(t0, t1));
+    b = fminf(b, fmaxf(t0, t1));
+    t0 = fmaf((float)(q.z & 0xFFFFu), sid.z, snoid.z);
+    t1 = fmaf((float)(q.z >> 16), sid.z, snoid.z);
+    a = fmaxf(a, fminf(t0, t1));
+    b = fminf(b, fmaxf(t0, t1));
+    a = fmaxf(a, tmin);
+    b = fminf(b, tmax);
+    tn = a;
+    return a <= b * 1.000002f + 1e-7f;
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool leaf_tris_lds(const float4* __restrict__ s_verts, const uint2* __restrict__ s_tidx, int first, int cnt, v3 o, v3 d, float tmin,
+                                              float tmax, int& best, int& best_pos, float& bt, float& bu, float& bv)
+{
+    uint2 ti[kLeafTris];
+#pragma unroll
+    for (int k = 0; k < kLeafTris; ++k) ti[k] = s_tidx[first + (k < cnt ? k : 0)];
+    float4 a[kLeafTris], b[kLeafTris], c[kLeafTris];
+#pragma unroll
+    for (int k = 0; k < kLeafTris; ++k) {
+        a[k] = s_verts[ti[k].x & 0xFFFFu];
+        b[k] = s_verts[ti[k].x >> 16];
+        c[k] = s_verts[ti[k].y & 0xFFFFu];
+    }
+#pragma unroll
+    for (int k = 0; k < kLeafTris; ++k) {
+        if (k < cnt) {
+            const int tri = (int)(ti[k].y >> 16);
+            float t, u, v;
+            if (tri_intersect(mk(a[k].x, a[k].y, a[k].z), mk(b[k].x, b[k].y, b[k].z), mk(c[k].x, c[k].y, c[k].z), o, d, tmin, tmax, t, u, v) &&
+                (t < bt || (t == bt && best >= 0 && tri < best))) {
+                bt = t;
+                bu = u;
+                bv = v;
+                best = tri;
+                best_pos = first + k;
+                if (ANY) return true;
+            }
+        }
+    }
+    return false;
+}
+
+template <bool ANY>
+__device__ __forceinline__ bool trace_lds(const Params& p, const uint4* __restrict__ s_q, const float4* __restrict__ s_verts, const uint2* __restrict__ s_tidx,
+                                          unsigned short* __restrict__ s_stack, int stride, v3 o, v3 d, float tmin, float tmax, int& tri_out, int& pos_out,
+                                          float& t_out, float& u_out, float& v_out)
+{
+    auto safe_inv = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : 1.0f / x; };
+    const v3 id = mk(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+    const v3 sid = mk(p.grid_step.x * id.x, p.grid_step.y * id.y, p.grid_step.z * id.z);
+    const v3 snoid = mk((p.grid_lo.x - o.x) * id.x, (p.grid_lo.y - o.y) * id.y, (p.grid_lo.z - o.z) * id.z);
+    int best = -1, best_pos = 0;
+    float bt = tmax, bu = 0.0f, bv = 0.0f;
+    if (p.n_recs == 0) {
+        leaf_tris_lds<ANY>(s_verts, s_tidx, 0, p.n_triangles, o, d, tmin, tmax, best, best_pos, bt, bu, bv);
+    } else {
+        // while-while: every lane first descends to its next leaf (or runs out of work), then the lanes that hold a leaf test it
+        int sp = 0;
+        int cur = 0;
+        bool have = true;
+        auto pop = [&]() {
+            have = sp > 0;
+            if (have) {
+                --sp;
+                const int e = (int)s_stack[sp * stride];
+                cur = (e & 0x8000) ? -1 - (e & 0x7FFF) : e;
+            }
+        };
+        while (have) {
+            while (have && cur >= 0) {
+                const uint4 L = s_q[2 * cur + 0], R = s_q[2 * cur + 1];
+                float tl, tr;
+                const bool hl = qbox_hit(L, sid, snoid, tmin, bt, tl);
+                const bool hr = qbox_hit(R, sid, snoid, tmin, bt, tr);
+                const int ll = (int)L.w, lr = (int)R.w;
+                const bool go_r = hr && (!hl || tr < tl);
+                if (hl && hr) {
+                    const int far = go_r ? ll : lr;
+                    s_stack[sp * stride] = (unsigned short)(far >= 0 ? far : (0x8000 | (-1 - far)));
+                    ++sp;
+                }
+                if (hl || hr) cur = go_r ? lr : ll;
+                else pop();
+            }
+            if (have) {
+                const int code = -1 - cur;
+                if (leaf_tris_lds<ANY>(s_verts, s_tidx, code & 0xFFF, (code >> 12) + 1, o, d, tmin, tmax, best, best_pos, bt, bu, bv)) break;   // (true only when ANY)
+                pop();
+            }
+        }
+    }
+    tri_out = best;
+    pos_out = best_pos;
+    t_out = bt;
+    u_out = bu;
+    v_out = bv;
+    return best >= 0;
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char w_smem[];
 #ifdef RTGO_WHITTED_TIMING
     const unsigned long long wt0 = wall_clock64();
     unsigned long long wt_tiles = 0, wt_n = 0, wt_max = 0;
-    unsigned int wt_stepmax = 0;
 #endif
+    // LDS image.  kRecordsInLds: [fp32 records, 64 B each][stacks];  kAllInLds: [quantised records, 32 B][vertices, 16 B][triangle
+    // indices, 8 B][stacks];  kAllInL2: [stacks]
     float4* s_recs = reinterpret_cast<float4*>(w_smem);
+    uint4* s_q = reinterpret_cast<uint4*>(w_smem);
+    float4* s_verts = reinterpret_cast<float4*>(s_q + 2 * p.n_recs);
+    uint2* s_tidx = reinterpret_cast<uint2*>(s_verts + p.n_vertices);
     const int stride = (int)blockDim.x;
-    unsigned short* s_stack = reinterpret_cast<unsigned short*>(s_recs + (RESIDENT ? 4 * p.n_recs : 0)) + threadIdx.x;   // entry e at [e * stride]
-    if (RESIDENT) {
+    unsigned short* s_stack = (MODE == kAllInLds ? reinterpret_cast<unsigned short*>(s_tidx + p.n_triangles)
+                                                 : reinterpret_cast<unsigned short*>(s_recs + (MODE == kRecordsInLds ? 4 * p.n_recs : 0))) + threadIdx.x;   // entry e at [e * stride]
+    if (MODE == kRecordsInLds) {
         for (int i = (int)threadIdx.x; i < 4 * p.n_recs; i += stride) s_recs[i] = p.recs[i];
+        __syncthreads();
+    }
+    if (MODE == kAllInLds) {
+        for (int i = (int)threadIdx.x; i < 2 * p.n_recs; i += stride) s_q[i] = p.qrecs[i];
+        for (int i = (int)threadIdx.x; i < p.n_vertices; i += stride) s_verts[i] = make_float4(p.positions[3 * i + 0], p.positions[3 * i + 1], p.positions[3 * i + 2], 0.0f);
+        for (int i = (int)threadIdx.x; i < p.n_triangles; i += stride) s_tidx[i] = p.tidx[i];
         __syncthreads();
     }
 #ifdef RTGO_WHITTED_TIMING
@@ -259,10 +383,21 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
 #endif
     if (blockIdx.x == 0 && threadIdx.x < (unsigned int)kTileHeads) p.tile_counter_next[kTileHeadStride * threadIdx.x] = 0u;
     auto pick = [&]() {
-        if constexpr (RESIDENT) return static_cast<const float4*>(s_recs);
+        if constexpr (MODE == kRecordsInLds) return static_cast<const float4*>(s_recs);
         else return p.recs;
     };
     const auto recs = pick();
+    // closest hit / any hit through whichever form of the structure this instantiation walks
+    auto closest = [&](v3 o, v3 d, float t0, float t1, int& tri, int& pos, float& t, float& u, float& v) -> bool {
+        if constexpr (MODE == kAllInLds) return trace_lds<false>(p, s_q, s_verts, s_tidx, s_stack, stride, o, d, t0, t1, tri, pos, t, u, v);
+        else return trace<false>(p, recs, s_stack, stride, o, d, t0, t1, tri, pos, t, u, v);
+    };
+    auto occluded = [&](v3 o, v3 d, float t0, float t1) -> bool {
+        int tri, pos;
+        float t, u, v;
+        if constexpr (MODE == kAllInLds) return trace_lds<true>(p, s_q, s_verts, s_tidx, s_stack, stride, o, d, t0, t1, tri, pos, t, u, v);
+        else return trace<true>(p, recs, s_stack, stride, o, d, t0, t1, tri, pos, t, u, v);
+    };
     const unsigned int lane = threadIdx.x & 63u;
     const unsigned int n_tiles = p.tiles_x * p.tiles_y;
     unsigned int rays = 0, occl = 0;
@@ -296,7 +431,6 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
 #ifdef RTGO_WHITTED_TIMING
         const unsigned long long wt2 = wall_clock64();
         wt_n += 1;
-        unsigned int wt_steps = 0;
 #endif
         const unsigned int ty = tile / p.tiles_x, tx = tile - ty * p.tiles_x;
         const unsigned int x = tx * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
@@ -317,21 +451,35 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
             int tri, tpos;
             float t, bu, bv;
             rays += 1;
-            if (trace<false>(p, recs, s_stack, stride, ro, rd, 0.01f, 1e16f, tri, tpos, t, bu, bv
-#ifdef RTGO_WHITTED_TIMING
-                             , wt_steps
-#endif
-                             )) {
+            if (closest(ro, rd, 0.01f, 1e16f, tri, tpos, t, bu, bv)) {
                 // __closesthit__radiance, :255-337, with getLocalGeometry (LocalGeometry.h:55-141) for a mesh in world space.
                 // (the corners come from the Morton-ordered copy the walk read them from: same values, no trip through the index array)
-                const float4 c0 = p.tris[3 * tpos + 0], c1 = p.tris[3 * tpos + 1], c2 = p.tris[3 * tpos + 2];
+                float4 c0, c1, c2;
+                unsigned int i0 = 0, i1 = 0, i2 = 0;   // vertex indices (for the normals)
+                if constexpr (MODE == kAllInLds) {
+                    const uint2 ti = s_tidx[tpos];
+                    i0 = ti.x & 0xFFFFu;
+                    i1 = ti.x >> 16;
+                    i2 = ti.y & 0xFFFFu;
+                    c0 = s_verts[i0];
+                    c1 = s_verts[i1];
+                    c2 = s_verts[i2];
+                } else {
+                    c0 = p.tris[3 * tpos + 0];
+                    c1 = p.tris[3 * tpos + 1];
+                    c2 = p.tris[3 * tpos + 2];
+                    if (p.normals) {
+                        i0 = p.indices[3 * tri + 0];
+                        i1 = p.indices[3 * tri + 1];
+                        i2 = p.indices[3 * tri + 2];
+                    }
+                }
                 const v3 P0 = mk(c0.x, c0.y, c0.z), P1 = mk(c1.x, c1.y, c1.z), P2 = mk(c2.x, c2.y, c2.z);
                 const float w0 = 1.0f - bu - bv;
                 const v3 P = vadd(vadd(vscale(P0, w0), vscale(P1, bu)), vscale(P2, bv));
                 const v3 Ng = vnormalize(vcross(vsub(P1, P0), vsub(P2, P0)));
                 v3 N = Ng;
                 if (p.normals) {
-                    const unsigned int i0 = p.indices[3 * tri + 0], i1 = p.indices[3 * tri + 1], i2 = p.indices[3 * tri + 2];
                     const v3 N0 = ld3(p.normals, i0), N1 = ld3(p.normals, i1), N2 = ld3(p.normals, i2);
                     N = vnormalize(vadd(vadd(vscale(N0, w0), vscale(N1, bu)), vscale(N2, bv)));
                 }
@@ -353,15 +501,9 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
                     const v3 H = vnormalize(vadd(Lv, Vv));
                     const float NdotL = vdot(N, Lv), NdotV = vdot(N, Vv), NdotH = vdot(N, H), VdotH = vdot(Vv, H);
                     if (NdotL > 0.0f && NdotV > 0.0f) {
-                        int ot, opos;
-                        float tt, uu, vv;
                         rays += 1;
                         occl += 1;
-                        if (!trace<true>(p, recs, s_stack, stride, P, Lv, 0.001f, Ldist - 0.001f, ot, opos, tt, uu, vv
-#ifdef RTGO_WHITTED_TIMING
-                                         , wt_steps
-#endif
-                                         )) {
+                        if (!occluded(P, Lv, 0.001f, Ldist - 0.001f)) {
                             const v3 F = schlick(spec_color, VdotH);
                             const float G = vis(NdotL, NdotV, alpha);
                             const float D = ggx_normal(NdotH, alpha);
@@ -390,17 +532,9 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
                                        (unsigned char)(powf(clampf(acc.z, 0.0f, 1.0f), g) * 255.0f), 255u);
         }
 #ifdef RTGO_WHITTED_TIMING
-        {
-            unsigned int mx = wt_steps;
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned int o2 = (unsigned int)__shfl_xor((int)mx, off, 64);
-                mx = o2 > mx ? o2 : mx;
-            }
-            wt_stepmax = mx > wt_stepmax ? mx : wt_stepmax;
-        }
         const unsigned long long wt3 = wall_clock64() + (rays == 0xFFFFFFFFu ? 1 : 0) - wt2;
         wt_tiles += wt3;
-        if (x < p.width && y < p.height) p.accum[y * p.width + x].w = (float)wt3 + 0.001f * (float)wt_steps;   // (diagnostic: ticks of the tile . steps of the pixel)
+        if (x < p.width && y < p.height) p.accum[y * p.width + x].w = (float)wt3;   // (diagnostic: ticks of the tile)
         wt_max = wt3 > wt_max ? wt3 : wt_max;
 #endif
     }
@@ -412,7 +546,6 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
 #ifdef RTGO_WHITTED_TIMING
         // diagnostic build (tools/whitted_perf.py prints them): 10 ns ticks summed over the waves
         atomicAdd(&p.counters[2], wall_clock64() - wt0);   // wave lifetime          -> rtgo_stats.node_visits
-        atomicMax(&p.counters[3], (unsigned long long)wt_stepmax);   // most walk steps of one pixel (its three rays) -> prim_tests
         atomicAdd(&p.counters[4], wt_tiles);               // inside tiles           -> hits
         atomicAdd(&p.counters[5], wt_n);                   // tiles                  -> dbg_fast_boxes
         atomicMax(&p.counters[6], wt_max);                 // the longest tile       -> dbg_fast_tests
@@ -425,12 +558,13 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
 // buildMeshAccels).  Same recipe as the analytic path's canonical tree: 30-bit Morton code of the centroid normalised to the
 // scene bounds, stable order by (code, triangle index), Karras 2012, one triangle per leaf, bottom-up fit.
 // Boxes are padded by 1e-4 of the scene's extent + 1e-6: the slab test rounds, the triangle test must never be cut off.
-// out_meta = {depth of the hierarchy, records of the walk, stack entries the walk needs}.
+// out_meta = {depth of the hierarchy, records of the walk, stack entries the walk needs, grid origin xyz, grid step xyz (float bits)}.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __restrict__ positions, const unsigned int* __restrict__ indices, int n,
                                                               float4* __restrict__ nodes, int* __restrict__ parent, int* __restrict__ visit,
                                                               int* __restrict__ first_of, int* __restrict__ count_of, int* __restrict__ rec_of,
-                                                              float4* __restrict__ recs, float4* __restrict__ tris, int* __restrict__ out_meta)
+                                                              float4* __restrict__ recs, float4* __restrict__ tris, uint4* __restrict__ qrecs,
+                                                              uint2* __restrict__ tidx, int* __restrict__ out_meta)
 {
     __shared__ unsigned long long s_keys[kMaxTriangles];
     __shared__ float s_red[6][kBuildThreads];
@@ -586,6 +720,12 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
     // them gets one record with BOTH children's boxes, so that a step of the walk reads 64 contiguous bytes.
     for (int i = tid; i < n - 1; i += kBuildThreads) rec_of[i] = count_of[i] > kLeafTris ? (i == 0 ? 0 : atomicAdd(&s_nrec, 1)) : -1;
     __syncthreads();
+    // grid of the compact form: cells 1 .. 65534 span the padded scene box
+    float glo[3], gstep[3];
+    for (int a = 0; a < 3; ++a) {
+        glo[a] = blo[a] - pad;
+        gstep[a] = (ext[a] + 2.0f * pad) * (1.0f / 65533.0f);
+    }
     auto link_of = [&](int child) -> int {
         if (child >= leaf0) return -1 - (child - leaf0);                                         // one triangle
         if (count_of[child] <= kLeafTris) return -1 - (first_of[child] | ((count_of[child] - 1) << 12));
@@ -600,6 +740,17 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
         recs[4 * r + 1] = make_float4(a1.x, a1.y, a1.z, 0.0f);
         recs[4 * r + 2] = make_float4(b0.x, b0.y, b0.z, __int_as_float(link_of(R)));
         recs[4 * r + 3] = make_float4(b1.x, b1.y, b1.z, 0.0f);
+        // the same record on the 16-bit grid over the padded scene box: lower planes one cell below their floor, upper planes one
+        // above their ceiling
+        auto cell = [&](float v, int a, bool up) -> unsigned int {
+            const float c = (v - glo[a]) / gstep[a];
+            const float q = up ? ceilf(c) + 1.0f : floorf(c) - 1.0f;
+            return (unsigned int)fminf(fmaxf(q, 0.0f), 65535.0f);
+        };
+        qrecs[2 * r + 0] = make_uint4(cell(a0.x, 0, false) | (cell(a1.x, 0, true) << 16), cell(a0.y, 1, false) | (cell(a1.y, 1, true) << 16),
+                                      cell(a0.z, 2, false) | (cell(a1.z, 2, true) << 16), (unsigned int)link_of(L));
+        qrecs[2 * r + 1] = make_uint4(cell(b0.x, 0, false) | (cell(b1.x, 0, true) << 16), cell(b0.y, 1, false) | (cell(b1.y, 1, true) << 16),
+                                      cell(b0.z, 2, false) | (cell(b1.z, 2, true) << 16), (unsigned int)link_of(R));
         int dd = 1;   // stack entries a walk can hold below this record: one per record on the way down, its own included
         for (int q = parent[i]; q >= 0; q = parent[q]) ++dd;
         atomicMax(&s_wdepth, dd);
@@ -610,12 +761,17 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
         tris[3 * i + 0] = make_float4(positions[3 * i0 + 0], positions[3 * i0 + 1], positions[3 * i0 + 2], __int_as_float((int)tri));
         tris[3 * i + 1] = make_float4(positions[3 * i1 + 0], positions[3 * i1 + 1], positions[3 * i1 + 2], 0.0f);
         tris[3 * i + 2] = make_float4(positions[3 * i2 + 0], positions[3 * i2 + 1], positions[3 * i2 + 2], 0.0f);
+        tidx[i] = make_uint2((i0 & 0xFFFFu) | (i1 << 16), (i2 & 0xFFFFu) | (tri << 16));   // (used only when every vertex index fits 16 bits)
     }
     __syncthreads();
     if (tid == 0) {
         out_meta[0] = s_depth;
         out_meta[1] = n > kLeafTris ? s_nrec : 0;   // 0: the mesh is one leaf, no records
         out_meta[2] = s_wdepth;
+        for (int a = 0; a < 3; ++a) {
+            out_meta[3 + a] = __float_as_int(glo[a]);
+            out_meta[6 + a] = __float_as_int(gstep[a]);
+        }
     }
 }
 

@@ -920,6 +920,31 @@ def test_whitted_triangles_against_the_oracle(capi, oracle, variant):
 
 
 @pytest.mark.gpu
+def test_whitted_the_three_residency_modes_agree(capi, oracle, monkeypatch):
+    """the render kernel walks one of three forms of the same structure -- everything in LDS on a 16-bit grid (what the other tests
+    run, the meshes being small enough), fp32 records in LDS with the triangles in L2, everything in L2: closest hits are
+    closest hits, so the three frames must be bitwise one frame"""
+    import whitted_scene
+    W, H = 160, 100
+    mesh = whitted_scene.build(n_lat=24, n_lon=32)
+    cam = whitted_scene.camera(oracle, W, H)
+    frames = []
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("RTGO_WHITTED_MODE", mode)
+        ctx = _whitted_ctx(capi, mesh, cam, W, H)
+        ctx.reset_stats()
+        for sf in range(3):
+            ctx.whitted_launch(W, H, sf)
+        ctx.sync()
+        frames.append((ctx.read_accum(H, W), ctx.read_image(H, W), ctx.stats()["rays_total"]))
+        ctx.close()
+    for acc, img, rays in frames[1:]:
+        assert np.array_equal(acc.view(np.uint32), frames[0][0].view(np.uint32)) and np.array_equal(img, frames[0][1]) and rays == frames[0][2]
+    racc, rimg, rc = oracle.whitted_render(mesh, cam, W, H, 3)
+    assert_parity(frames[0][0], racc, frames[0][1], rimg, what="whitted, three modes")
+
+
+@pytest.mark.gpu
 def test_whitted_against_the_committed_fixture(capi):
     """tests/golden/oracle_whitted.npz: the GPU against stored oracle output (no oracle run needed)"""
     import whitted_scene

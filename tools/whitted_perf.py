@@ -44,15 +44,10 @@ if st["node_visits"]:
     waves = min((((W + 7) // 8) * ((H + 7) // 8) + 15) // 16, 256) * 16
     print("  diagnostic build: per wave and launch: alive %.1f us, inside tiles %.1f us, %.1f tiles" %
           (st["node_visits"] / K / waves / 100.0, st["hits"] / K / waves / 100.0, st["dbg_fast_boxes"] / K / waves))
-    print("  longest tile of the %d launches: %.1f us; most walk steps of one pixel: %d" % (K, st["dbg_fast_tests"] / 100.0, st["prim_tests"]))
-    acc = ctx.read_accum(H, W)[..., 3]
-    ticks = np.floor(acc)[::8, ::8] / 100.0       # one value per tile, us
-    steps = np.round((acc - np.floor(acc)) * 1000.0)
+    print("  longest tile of the %d launches: %.1f us" % (K, st["dbg_fast_tests"] / 100.0))
+    ticks = ctx.read_accum(H, W)[::8, ::8, 3] / 100.0       # one value per tile, us
     print("  tile duration [us]: p50 %.1f p90 %.1f p99 %.1f max %.1f; tiles over 100 us: %d of %d" %
           (np.percentile(ticks, 50), np.percentile(ticks, 90), np.percentile(ticks, 99), ticks.max(), (ticks > 100).sum(), ticks.size))
-    ys, xs = np.nonzero(ticks > 0.5 * ticks.max())
-    for yy, xx in list(zip(ys, xs))[:12]:
-        print("    slow tile (%d, %d): %.1f us, steps of its pixels: max %d mean %.1f" % (xx, yy, ticks[yy, xx], steps[8*yy:8*yy+8, 8*xx:8*xx+8].max(), steps[8*yy:8*yy+8, 8*xx:8*xx+8].mean()))
     th, tw = ticks.shape
     print("  map of tile durations (rows top to bottom; . < 25 us, - < 50, + < 100, * < 200, # more):")
     for yy in range(th - 1, -1, -max(1, th // 34)):
