@@ -33,7 +33,7 @@ for seed in range(first, first + count):
         U, V, Wv = [np.zeros(3, dtype=np.float32) for _ in range(3)]
         O.lib().oracle_camera_uvw(O.fptr(eye), O.fptr(look), O.fptr(up), float(rng.uniform(10.0, 120.0)), np.float32(np.float32(W) / np.float32(H)), O.fptr(U), O.fptr(V), O.fptr(Wv))
         ctx.set_camera(eye, U, V, Wv)
-        n = int(rng.choice([1, 2, 3, 5])); frame = int(rng.choice([0, 3])); path = bool(rng.integers(0, 2)); amb = bool(rng.integers(0, 2)) and not path
+        n = int(rng.choice([1, 2, 3, 5, 6, 9])); frame = int(rng.choice([0, 3])); path = bool(rng.integers(0, 2)); amb = bool(rng.integers(0, 2)) and not path
         md = int(rng.choice([5, 5, 2]))
         win = None if rng.integers(0, 2) else (int(rng.integers(0, 40)), int(rng.integers(0, 30)), int(rng.integers(1, 56)), int(rng.integers(1, 34)))
         G = int(rng.choice([1, 1, 2, 3])); g = int(rng.integers(0, G))
