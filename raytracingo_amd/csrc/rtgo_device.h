@@ -882,6 +882,9 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     const unsigned int group_base = (pl < P ? pl : 0u) * nn_eff;
 
     unsigned int c_rays = 0, c_occl = 0, c_nodes = 0, c_tests = 0, c_hits = 0;
+#ifdef RTGO_STREAM_STATS
+    unsigned long long ss_iter = 0, ss_trace = 0, ss_shade_rounds = 0, ss_shade = 0, ss_stall = 0;   // diagnostic: streaming-loop census
+#endif
 
     // Work queue: kQueues heads, 64 bytes apart; head q serves the entries u with u % kQueues == q.  A wave pulls from the head
     // blockIdx % kQueues and, when that runs dry, from the others.  One head saturates at ~88 dequeues/us chip-wide
@@ -1014,7 +1017,8 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
             tl_lanes += (unsigned long long)__popcll(__ballot(active));
 #endif
             if (active) {
-#include "rtgo_ray_step.inc"
+#include "rtgo_ray_trace.inc"
+#include "rtgo_ray_shade.inc"
             }
 #ifdef RTGO_TIMELINE
             tl_loop += wall_clock64() + (result.x == 12345.0f ? 1 : 0) - tl_i0;
@@ -1033,16 +1037,23 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         }
         }  // pass
         } else {
-            // STREAM (frames of more than 16 spp: several passes per pixel).  In open scenes most paths end after a ray or two while a
-            // few go on for six: run pass by pass in lock-step, the wave would trace four more iterations for a handful of lanes,
-            // sixteen times per pixel at 256 spp.  Here a lane whose path has ended starts its NEXT sample (same pixel, next pass)
-            // while the others go on -- wavefront compaction in time rather than across lanes: no state moves, the lane keeps its
-            // registers.  New samples start in batches (>= kRegenBatch idle lanes, found by __ballot, or nobody active) so that the
-            // raygen code runs with lanes to fill it.  The payloads wait in a window of kWin passes in LDS and are added pass by
-            // pass, in sample order (kernel.cu:232), as soon as every sample of the oldest open pass has ended.
-            constexpr unsigned int kWin = (unsigned int)kStreamWindow, kRegenBatch = 4u;
-            float* s_win = s_win_base;
-            unsigned int my_pass = 0u, fold_pass = 0u;
+            // STREAM (frames of more than 16 spp).  The unit's work is a list of TASKS, one per (pixel, sample): task t is sample
+            // t / npx of the unit's pixel t % npx.  Any lane whose path has ended takes the next task -- lanes are not tied to a pixel
+            // or to a sample slot -- so the samples of the one pixel of the unit that sees the scene spread over all 64 lanes while
+            // the pixels that see the background cost one ray each (lock-step: the wave traces the longest path of every pass, sixteen
+            // passes at 256 spp, with most lanes idle after the first ray).  New tasks start in batches (>= kRegenBatch idle lanes
+            // by __ballot, or nobody active) so that the raygen code runs with lanes to fill it.  A finished path parks its payload
+            // in a ring in LDS (slot t % kRing; the slot holds a "pending" pattern from the moment the task is taken); the lanes
+            // 0 .. npx-1 own one pixel each and add the payloads of its tasks in task order = sample order (kernel.cu:232) as the
+            // completed prefix of the list grows, so the pixel is bit for bit the lock-step one.
+            constexpr unsigned int kRing = 64u * (unsigned int)kStreamWindow, kRegenBatch = 4u;
+            constexpr unsigned int kPending = 0x7FC0DEADu;   // a NaN no computation produces
+            float* s_ring = s_win_base;                      // x at [slot], y at [kRing + slot], z at [2 kRing + slot]
+            const unsigned int px_left = p.w - (strip_x0 + ui * P);
+            const unsigned int npx = px_left < P ? px_left : P;
+            const unsigned int n_tasks = nn * npx;
+            unsigned int t_next = 0u, fold_ptr = 0u;   // wave-uniform: tasks taken so far, tasks folded so far
+            unsigned int my_slot = 0u;
         bool active;
         int depth;
         int phase;                     // distributed mode: 0 = radiance ray in flight, 1 = shadow ray in flight
@@ -1071,45 +1082,76 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                 lvA[q] = mk(0, 0, 0);
                 lvPrim[q] = 0;
             }
-            for (;;) {
-                const bool idle = !active && in_range && (my_pass * nn_eff + kl) < nn && my_pass < fold_pass + kWin;
-                const unsigned long long m_idle = __ballot(idle), m_act = __ballot(active);
-                if (m_idle != 0ull && (m_act == 0ull || (unsigned int)__popcll(m_idle) >= kRegenBatch)) {
-                    if (idle) {
-                        const unsigned int k = my_pass * nn_eff + kl;
+            while (fold_ptr < n_tasks) {
+                // ---- idle lanes take the next tasks, in lane order
+                const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(!active), m_act = ~m_idle;
+                const unsigned int room = kRing - (t_next - fold_ptr);
+                unsigned int n_take = (unsigned int)__popcll(m_idle);
+                n_take = n_take < n_tasks - t_next ? n_take : n_tasks - t_next;
+                n_take = n_take < room ? n_take : room;
+                if (n_take != 0u && (m_act == 0ull || n_take >= kRegenBatch || t_next + n_take == n_tasks)) {
+                    const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(m_idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m_idle, 0u));
+                    // (every lane computes its would-be task: the seed exchange below needs the whole wave)
+                    const unsigned int t = t_next + rank;
+                    const unsigned int k = npx == 4u ? (t >> 2) : t / npx;   // (the usual unit: four pixels)
+                    const unsigned int j = t - k * npx;
+                    const unsigned int pix0 = (unsigned int)__shfl((int)strip_seed, (int)((ui * P + j) & 63u), 64);
+                    if (!active && rank < n_take) {
+                        const float fx = (float)(p.x0 + strip_x0 + ui * P + j);
+                        const bool in_range = true;
+                        my_slot = t & (kRing - 1u);
+                        s_ring[my_slot] = __uint_as_float(kPending);
 #include "rtgo_start_sample.inc"
                     }
+                    t_next += n_take;
                 }
-                if (__ballot(active) != 0ull) {
+                // ---- one ray for every lane that has a path
+                if (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+#ifdef RTGO_STREAM_STATS
+                    ss_iter += 1;
+                    ss_trace += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(active));
+                    if (room == 0u && m_idle != 0ull && t_next < n_tasks) ss_stall += 1;
+#endif
                     const bool was = active;
                     if (active) {
-#include "rtgo_ray_step.inc"
+#include "rtgo_ray_trace.inc"
+#ifdef RTGO_STREAM_STATS
+                        if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
+                            ss_shade_rounds += 1;
+                            ss_shade += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(hit));
+                        }
+#endif
+#include "rtgo_ray_shade.inc"
                     }
                     if (was && !active) {
-                        const unsigned int slot = (my_pass % kWin) * 192u + (unsigned int)lane;
-                        s_win[slot] = result.x;
-                        s_win[slot + 64u] = result.y;
-                        s_win[slot + 128u] = result.z;
-                        ++my_pass;
+                        s_ring[kRing + my_slot] = result.y;
+                        s_ring[2u * kRing + my_slot] = result.z;
+                        s_ring[my_slot] = result.x;
                     }
                 }
-                while (fold_pass < passes) {
-                    // a lane still owes the oldest open pass while it has a sample there that has not ended
-                    const bool owes = in_range && (fold_pass * nn_eff + kl) < nn && my_pass <= fold_pass;
-                    if (__ballot(owes) != 0ull) break;
-                    const unsigned int cnt = (nn - fold_pass * nn_eff) < nn_eff ? (nn - fold_pass * nn_eff) : nn_eff;
-                    const unsigned int slot = (fold_pass % kWin) * 192u;
-                    for (unsigned int q = 0; q < cnt; ++q) {
-                        const unsigned int src = slot + group_base + q;
-                        color = vadd(color, mk(s_win[src], s_win[src + 64u], s_win[src + 128u]));
+                // ---- the completed prefix of the task list goes into the pixels
+                {
+                    const unsigned int probe = fold_ptr + (unsigned int)lane;
+                    const bool ready = probe < t_next && __float_as_uint(s_ring[probe & (kRing - 1u)]) != kPending;
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(ready);
+                    const unsigned int n_ready = m == ~0ull ? 64u : (unsigned int)__builtin_ctzll(~m);
+                    const bool must = t_next == n_tasks || (t_next - fold_ptr) + 64u > kRing;   // nothing left to take / the ring is filling up
+                    if (n_ready >= 32u || (must && n_ready != 0u)) {
+                        if ((unsigned int)lane < npx) {
+                            unsigned int t = fold_ptr + (((unsigned int)lane + npx - fold_ptr % npx) % npx);   // this pixel's first task in the prefix
+                            for (; t < fold_ptr + n_ready; t += npx) {
+                                const unsigned int slot = t & (kRing - 1u);
+                                color = vadd(color, mk(s_ring[slot], s_ring[kRing + slot], s_ring[2u * kRing + slot]));
+                            }
+                        }
+                        fold_ptr += n_ready;
                     }
-                    ++fold_pass;
                 }
-                if (fold_pass >= passes) break;
             }
+            if ((unsigned int)lane < npx) write_pixel(p, (size_t)lr * p.w + strip_x0 + ui * P + (unsigned int)lane, vscale(color, 1.0f / (float)nn));
         }
 
-
+        if constexpr (!STREAM)
         if (in_range && kl == 0) {
             // kernel.cu:236-246.  float3 / float multiplies by the reciprocal (vec_math.h:479-483)
             write_pixel(p, (size_t)lr * p.w + lx, vscale(color, 1.0f / (float)nn));
@@ -1145,6 +1187,15 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
             atomicAdd(&p.counters[5], (unsigned long long)c_nodes);
             atomicAdd(&p.counters[6], (unsigned long long)c_tests);
         }
+    }
+#endif
+#ifdef RTGO_STREAM_STATS
+    if (lane == 0 && !STATS) {
+        atomicAdd(&p.counters[2], ss_iter);          // -> node_visits
+        atomicAdd(&p.counters[3], ss_trace);         // -> prim_tests
+        atomicAdd(&p.counters[4], ss_shade_rounds);  // -> hits
+        atomicAdd(&p.counters[5], ss_shade);         // -> dbg_fast_boxes
+        atomicAdd(&p.counters[6], ss_stall);         // -> dbg_fast_tests
     }
 #endif
     if (lane == 0) {
