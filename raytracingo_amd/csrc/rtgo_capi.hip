@@ -254,6 +254,7 @@ extern "C" int rtgo_debug_cmpwalk(rtgo_ctx* c, void* host, size_t bytes)
     const size_t n = 256 * 16 * sizeof(float);
     if (hipMemcpy(host, c->d_cmp, n < bytes ? n : bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (hipMemset(c->d_cmp, 0, n) != hipSuccess) return -1;
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return -1;
     return 0;
 }
 #endif
@@ -731,6 +732,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (!c->d_cmp) {
         RTGO_HIP(c, hipMalloc(&c->d_cmp, 256 * 16 * sizeof(float)));
         RTGO_HIP(c, hipMemset(c->d_cmp, 0, 256 * 16 * sizeof(float)));
+        RTGO_HIP(c, hipStreamSynchronize(nullptr));   // (null-stream memset: the launch stream does not wait for it)
     }
     p.cmp = c->d_cmp;
 #endif

@@ -64,6 +64,10 @@ void* Malloc(size_t bytes)
     void* p = nullptr;
     hipCheck(hipMalloc(&p, bytes), "hipMalloc");
     hipCheck(hipMemset(p, 0, bytes), "hipMemset");
+    // hipMemset of device memory is asynchronous on the null stream, and the streams this renderer works on do not wait for that
+    // stream: without this the zeros could land AFTER the first kernel that writes the buffer (seen once in ~10 runs of the GPU suite:
+    // ReadAccum allocates its gather buffers on first use and reads all zeros)
+    hipCheck(hipStreamSynchronize(nullptr), "hipStreamSynchronize");
     return p;
 }
 void Free(void* p) { (void)hipFree(p); }
