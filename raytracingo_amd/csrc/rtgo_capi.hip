@@ -56,6 +56,8 @@ struct rtgo_ctx {
     int fast_depth = 0;
     int n_small = 0;
     int n_fnodes = 0;             // nodes of the fast walk's tree
+    int list_cub = 0;             // the up-front list starts with a certified box (1) / room (2): cuboid_range
+    float cub_a = 0.0f, cub_b = 0.0f;   // its margin = kCuboidTol + K (cub_a R + cub_b), R = reach of the launch's rays
     int n_big_pairs = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};  // tight world bounds of the scene (min xyz, max xyz)
     float* d_tight = nullptr;              // the fast walk's box of every primitive (device), and its host copy
@@ -449,9 +451,9 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), kBuildDynLds, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
-                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight);
+                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight, std::getenv("RTGO_NO_CUBOID") ? 0 : 1);
     RTGO_HIP(c, hipGetLastError());
-    int meta[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int meta[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     c->tight.assign((size_t)n * 6, 0.0f);
     RTGO_HIP(c, hipMemcpyAsync(c->tight.data(), c->d_tight, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -460,11 +462,17 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     c->lbvh_depth = depth;
     c->fast_depth = meta[1];
     c->n_small = meta[2];
-    c->n_big_pairs = meta[9];
+    c->n_big_pairs = meta[9] & 0xFF;
+    c->list_cub = meta[9] >> 8;
+    std::memcpy(&c->cub_a, &meta[11], sizeof(float));
+    std::memcpy(&c->cub_b, &meta[12], sizeof(float));
     c->n_fnodes = meta[10];
     if (c->n_fnodes < 0 || c->n_fnodes > 2 * (int)n - 1 || (c->n_small > 0 && c->n_fnodes < 1))
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: the fast walk's tree has " + std::to_string(c->n_fnodes) + " nodes");
     std::memcpy(c->bounds, &meta[3], sizeof c->bounds);
+    if (std::getenv("RTGO_DEBUG"))
+        std::fprintf(stderr, "rtgo_set_scene: %d primitives, %d in the fast walk's tree (%d nodes, depth %d), %d up front (%d pairs, cuboid certificate %d), margin coefficients %g %g, canonical LBVH depth %d\n",
+                     (int)n, c->n_small, c->n_fnodes, c->fast_depth, (int)n - c->n_small, c->n_big_pairs, c->list_cub, c->cub_a, c->cub_b, depth);
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
                                                std::to_string(kStackDepth) + ")");
@@ -605,6 +613,17 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         const float e[3] = {p.eye.x, p.eye.y, p.eye.z};
         for (int k = 0; k < 3; ++k) reach = std::fabs(e[k]) > reach ? std::fabs(e[k]) : reach;
         if (!(reach <= 500.0f)) canon = true;
+        // cuboid_range's margin, in the object-space y units of a face g: the certificate's tolerance plus the rounding of what is
+        // compared -- the reference's (u, v) on a face f, carried into y_g units by L_fg, and y_g(t_f) itself.  Each is a handful of
+        // float operations on terms no larger than |row| (|o| + t |d|) + |w| <= |row|_1 * 3 reach + |w| (origins within `reach`, hit
+        // points within the scene: t |d| <= 2 reach), i.e. <= 12 * 2^-24 of them; K = 64 * 2^-24 leaves five times that, and the
+        // build's A, B = max over (f, g) of L_fg |row_f|_1 + |row_g|_1 and of L_fg |w_f| + |w_g|.
+        p.cub_mu = kCuboidTol + 64.0f * 5.9604645e-8f * (c->cub_a * 3.0f * reach + c->cub_b);
+        p.list_cub = c->list_cub;
+        if (!(p.cub_mu < 0.02f)) {   // (tiny faces far from the origin: the margin would let two faces through too often to pay)
+            p.list_cub = 0;
+            p.cub_mu = -1.0f;        // tree leaves: cuboid_range is not taken either (see render_kernel)
+        }
     }
     const uint32_t lr0 = owned_rows_below(wy0, p.band_h, p.n_ranks, p.rank), lr1 = owned_rows_below(wy1, p.band_h, p.n_ranks, p.rank);
     const uint64_t units_hot = (uint64_t)((wx1 - wx0 + unit_px - 1) / unit_px) * (lr1 - lr0);

@@ -48,6 +48,8 @@ struct LaunchParams {
     int stack_depth;                // per-lane LDS stack entries this launch needs
     int n_small;                    // fast walk: fprims [0, n_small) are in the tree, [n_small, n_prims) are tested up front
     int n_big_pairs;                // ... of which the first 2*n_big_pairs records are pairs of opposite rectangles (pair_test)
+    int list_cub;                   // 1 / 2: the up-front list starts with three pairs certified as one box / one room (cuboid_range), 0: it does not
+    float cub_mu;                   // cuboid_range's margin for this launch (object-space units of a face's y axis)
     const LightRec* lights;
     float4* accum;
     uchar4* image;
@@ -380,6 +382,7 @@ struct FastHit {
     int orig;  // its SBT index (tie-break + material lookup)
 };
 constexpr int kFlat = 0x10000;
+constexpr float kCuboidTol = 1e-4f;   // cuboid certificate: how far (in a face's object-space y) another face's corner may be on the wrong side of its plane
 
 // the acceptance rule of SURVEY a14 (tmin < t < current closest; ties keep the lower SBT index), without branches
 __device__ __forceinline__ bool closer(float t, int orig, float tmin, const FastHit& best)
@@ -391,13 +394,11 @@ __device__ __forceinline__ bool closer(float t, int orig, float tmin, const Fast
 // result is committed through selects.  The lanes of a wave carry unrelated rays once paths have bounced, so some lane needs every
 // stage of the test anyway; nesting the stages in branches then only adds exec-mask bookkeeping and idle lanes.  `facing` (d.y < 0 in
 // object space, evaluated by the caller) and the other conditions of the reference enter as predicates.
+// second half of the rectangle test for the lanes in `c` (everything up to t > 0.0001 and the closest-hit rule has passed): the hit
+// point against the unit square, and the commit through selects
 template <typename Ptr>
-__device__ __forceinline__ void rect_commit(Ptr rec, const float4 r1, float dy, bool facing, int pos, int orig, v3 wo, v3 wd, float tmin, FastHit& best)
+__device__ __forceinline__ void rect_finish(Ptr rec, float t, bool c, int pos, int orig, v3 wo, v3 wd, FastHit& best)
 {
-    const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
-    // oy > 0 with d.y < 0 is the only way to t > 0 (so d.y != 0 and t > 1e-4 can hold); lanes that fail carry garbage in t
-    const float t = (0.0f - oy) / dy;
-    bool c = facing & (oy > 0.0f) & (t > 0.0001f) & closer(t, orig, tmin, best);
     if (__ballot(c) == 0ull) return;   // (coherent waves -- primary rays -- often leave here together)
     const float4 r0 = rec[0], r2 = rec[2];
     const float dx = r0.x * wd.x + r0.y * wd.y + r0.z * wd.z, dz = r2.x * wd.x + r2.y * wd.y + r2.z * wd.z;
@@ -408,6 +409,16 @@ __device__ __forceinline__ void rect_commit(Ptr rec, const float4 r1, float dy, 
     best.t = c ? t : best.t;
     best.pos = c ? (pos | kFlat) : best.pos;
     best.orig = c ? orig : best.orig;
+}
+
+template <typename Ptr>
+__device__ __forceinline__ void rect_commit(Ptr rec, const float4 r1, float dy, bool facing, int pos, int orig, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+    const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
+    // oy > 0 with d.y < 0 is the only way to t > 0 (so d.y != 0 and t > 1e-4 can hold); lanes that fail carry garbage in t
+    const float t = (0.0f - oy) / dy;
+    const bool c = facing & (oy > 0.0f) & (t > 0.0001f) & closer(t, orig, tmin, best);
+    rect_finish(rec, t, c, pos, orig, wo, wd, best);
 }
 
 template <typename Ptr>
@@ -526,6 +537,70 @@ __device__ __forceinline__ void leaf_range(Ptr fp, const float4* __restrict__ ld
     }
 }
 
+// Three rectangle pairs that the build has certified as the faces of ONE cuboid -- a box seen from outside (rectangles facing away
+// from it: every point of face f lies at or below the plane of every face g of the other two pairs, y_g <= tol in g's object space) or a
+// room seen from inside (facing into it: y_g >= -tol).  pair_test's argument says at most one face of a pair is front-facing; this one
+// says at most one of the three front-facing faces can be HIT: the point where the ray meets face f's plane has to lie on the inner
+// side of the other front-facing planes, or it is outside f's square.  So the first halves of the three tests run as in
+// kernel.cu:372-400 (same operations: d.y, o.y, t = -o.y / d.y for the front-facing face of each pair), then a face is dropped when
+// that point, o + t_f d, is beyond another front-facing plane by more than `mu` -- y_g(t_f) = o.y_g + t_f d.y_g from the values
+// already at hand -- and the second half (the other two rows of M^-1, the unit-square test, kernel.cu:401-414) runs ONCE, on the face
+// that is left, instead of three times.  Near an edge two faces can be left: a wave-level vote runs the second half again for those.
+// mu covers the certificate's tolerance and the rounding of the reference's u, v and of y_g (rtgo_capi.hip, cub_mu): a face the
+// reference accepts is never dropped, and a face that is not dropped gets the reference's whole test, so the closest hit is the same.
+// mu_out / mu_in: drop when y > mu_out or y < mu_in (box: (mu, -inf); room: (+inf, -mu)).
+template <bool LIST, typename Ptr>
+__device__ __forceinline__ void cuboid_range(Ptr fp, const float4* __restrict__ lds, int first, float mu_out, float mu_in, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+    float t[3], oy[3], dy[3];
+    bool front[3], ok[3], second[3];   // second: the pair's front-facing face is its second record
+    bool both = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pos = first + 2 * k;
+        const float4 r1a = fp[4 * pos + 1], r1b = fp[4 * pos + 5];
+        const float dya = r1a.x * wd.x + r1a.y * wd.y + r1a.z * wd.z;
+        const float dyb = r1b.x * wd.x + r1b.y * wd.y + r1b.z * wd.z;
+        const bool fa = dya < 0.0f, fb = dyb < 0.0f;
+        both = both | (fa & fb);
+        second[k] = !fa;
+        const float4 r1 = lds[4 * (fa ? pos : pos + 1) + 1];   // (a per-lane read of the one row: cheaper than holding both for selects)
+        dy[k] = fa ? dya : dyb;
+        oy[k] = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
+        t[k] = (0.0f - oy[k]) / dy[k];
+        front[k] = fa != fb;
+        ok[k] = front[k] & (oy[k] > 0.0f);
+    }
+    // rounding can let both faces of a pair through the sign test (the ray all but parallel to them): those lanes take the six
+    // single tests and nothing else
+    if (__ballot(both) != 0ull) {
+        if (both) {
+#pragma unroll 1
+            for (int k = 0; k < 6; ++k) leaf_test(lds, first + k, wo, wd, tmin, best);
+        }
+    }
+    auto beyond = [&](int f, int g) {
+        const float y = oy[g] + t[f] * dy[g];
+        return front[g] & ((y > mu_out) | (y < mu_in));
+    };
+    bool s0 = ok[0] & !both & !beyond(0, 1) & !beyond(0, 2);
+    bool s1 = ok[1] & !both & !beyond(1, 0) & !beyond(1, 2);
+    bool s2 = ok[2] & !both & !beyond(2, 0) & !beyond(2, 1);
+#pragma unroll 1
+    for (;;) {
+        const bool any = s0 | s1 | s2;
+        if (__ballot(any) == 0ull) break;
+        const float tt = s0 ? t[0] : (s1 ? t[1] : t[2]);
+        const int ps = first + (s0 ? (second[0] ? 1 : 0) : (s1 ? (second[1] ? 3 : 2) : (second[2] ? 5 : 4)));
+        s2 = s2 & (s0 | s1);
+        s1 = s1 & s0;
+        s0 = false;
+        const int orig = __float_as_int(lds[4 * ps + 3].y);
+        const bool c = any & (tt > 0.0001f) & closer(tt, orig, tmin, best);
+        rect_finish(lds + 4 * ps, tt, c, ps, orig, wo, wd, best);
+    }
+}
+
 // conservative slab test: t = fma(b, 1/d, -o/d) with the hardware reciprocal
 __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id, v3 noid, float tmin, float tmax, float& tn_out)
 {
@@ -550,7 +625,7 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
                                                  const float4* __restrict__ g_fprims,
  unsigned int* __restrict__ s_stack, int bshift,
-                                                 int n_small, int n_prims, int n_big_pairs, v3 o, v3 d, float tmin, float tmax, Hit& out,
+                                                 int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests
 #ifdef RTGO_TIMELINE
                                                  , unsigned long long& tl_big, unsigned long long& tl_tree
@@ -571,7 +646,13 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     // g_fprims is a read-only kernel argument, so the records arrive by scalar loads (s_load_dwordx4) into SGPRs: no LDS
     // traffic, no VGPRs for the matrices, and the loads of the next primitives overlap the tests of the current ones.
     // It also gives every ray a closest-hit bound before it enters the tree.
-    leaf_range<true>(g_fprims, s_fprims, n_small, n_prims - n_small, n_big_pairs, o, d, tmin, best);
+    if (list_cub != 0) {
+        // the room's six walls (or one big box) as a cuboid, the rest of the list after them
+        cuboid_range<true>(g_fprims, s_fprims, n_small, list_cub == 1 ? cub_mu : INFINITY, list_cub == 1 ? -INFINITY : -cub_mu, o, d, tmin, best);
+        leaf_range<true>(g_fprims, s_fprims, n_small + 6, n_prims - n_small - 6, 0, o, d, tmin, best);
+    } else {
+        leaf_range<true>(g_fprims, s_fprims, n_small, n_prims - n_small, n_big_pairs, o, d, tmin, best);
+    }
 #ifdef RTGO_FAST_COUNTERS
     dbg_tests += (unsigned int)(n_prims - n_small);
 #endif
@@ -637,11 +718,12 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
             }
         }
         if (have) {
-            const int first = left, cnt = (-right) & 0xFFF, npairs = (-right) >> 12;   // leaf link = -(count | pairs << 12)
+            const int first = left, cnt = (-right) & 0xFFF, npairs = ((-right) >> 12) & 0xFF;   // leaf link = -(count | pairs << 12 | cuboid << 20)
 #ifdef RTGO_FAST_COUNTERS
             dbg_tests += (unsigned int)cnt;
 #endif
-            leaf_range<false>(s_fprims, s_fprims, first, cnt, npairs, o, d, tmin, best);
+            if (((-right) >> 20) != 0 && cub_mu > 0.0f) cuboid_range<false>(s_fprims, s_fprims, first, cub_mu, -INFINITY, o, d, tmin, best);
+            else leaf_range<false>(s_fprims, s_fprims, first, cnt, npairs, o, d, tmin, best);
             have = pop();
         }
     }
@@ -1302,13 +1384,13 @@ __device__ __forceinline__ int lbvh_delta(const unsigned long long* keys, int n,
 // have_aabb, else written); out_fnodes / out_fprims: the fast walk's tree (2*n_small-1 nodes) and Morton-ordered records
 // (small primitives first, then the "big" ones that are tested up front);
 // out_tight: n x 6 floats, the fast walk's box of every primitive (SBT order);
-// out_meta = {canonical depth, fast-walk stack depth, n_small, tight scene bounds (6 floats as bits), pairs in the up-front list,
-// nodes of the fast walk's tree}.
+// out_meta = {canonical depth, fast-walk stack depth, n_small, tight scene bounds (6 floats as bits), pairs in the up-front list
+// | cuboid certificate of the list << 8, nodes of the fast walk's tree, the two coefficients of cuboid_range's margin (float bits)}.
 __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restrict__ prims, float* __restrict__ aabb_io,
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
                                                           float4* __restrict__ out_fprims, int leaf_budget, float big_frac, int* __restrict__ out_meta,
-                                                          float* __restrict__ out_tight)
+                                                          float* __restrict__ out_tight, int cuboids)
 {
     __shared__ float s_box[kMaxPrims][6];               // per primitive: reference AABB, later the tight box
     __shared__ unsigned long long s_keys[kMaxPrims];
@@ -1613,9 +1695,12 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
             s_used[i] = 0;
             s_visit[i] = 0;   // (build_tree's arrival counters are no longer needed: pairs per node from here on)
         }
+        __shared__ int s_cubA, s_cubB;   // cuboid_range's margin coefficients (positive floats as bits: integer max = float max)
         if (i == 0) {
             out_meta[9] = 0;
             s_count = 0;   // leaves that do not pair up completely
+            s_cubA = 0;
+            s_cubB = 0;
         }
         __syncthreads();
         int g_lo = 0, g_hi = -1;
@@ -1659,11 +1744,53 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
                     }
                 }
                 const int npairs = (out - g_lo) / 2;
+                // Cuboid certificate (cuboid_range): three pairs -- a whole leaf, or the pairs of the up-front list -- are the faces
+                // of one box seen from outside when the four corners of every face f lie at or below the plane of every face g of
+                // the other two pairs (y_g <= tol in g's object space; y_g is affine, so the whole face does), of one room seen from
+                // inside when they lie at or above it.  Checked on the matrices themselves: whatever passes is safe, whatever the
+                // shapes were meant to be.  L = how far y_g varies over face f: it carries the rounding of the reference's (u, v) on
+                // f into y_g units; A, B: margin = tol + K (A R + B) for rays within R of the origin (rtgo_capi.hip).
+                int cert = 0;
+                if (cuboids && npairs == 3 && (list || g_hi - g_lo + 1 == 6)) {
+                    bool outw = true, inw = true;
+                    float A = 0.0f, B = 0.0f;
+                    auto n1 = [](const float4 r) { return fabsf(r.x) + fabsf(r.y) + fabsf(r.z); };
+                    for (int f = 0; f < 6; ++f) {
+                        const int pf = (int)s_order[g_lo + f];
+                        const float* M = prims[pf].M;
+                        const float4 f0 = out_prims[6 * pf + 0], f2 = out_prims[6 * pf + 2];
+                        const float n1f = fmaxf(n1(f0), n1(f2)), wf = fmaxf(fabsf(f0.w), fabsf(f2.w));
+                        for (int g = 0; g < 6; ++g) {
+                            if ((g >> 1) == (f >> 1)) continue;
+                            const float4 r1 = out_prims[6 * (int)s_order[g_lo + g] + 1];
+                            float ymax = -INFINITY, ymin = INFINITY;
+                            for (int c = 0; c < 4; ++c) {
+                                const float sx = (c & 1) ? 0.5f : -0.5f, sz = (c & 2) ? 0.5f : -0.5f;
+                                const float cx = M[0] * sx + M[2] * sz + M[3], cy = M[4] * sx + M[6] * sz + M[7], cz = M[8] * sx + M[10] * sz + M[11];
+                                const float y = r1.x * cx + r1.y * cy + r1.z * cz + r1.w;
+                                ymax = fmaxf(ymax, y);
+                                ymin = fminf(ymin, y);
+                                if (!(y == y)) outw = inw = false;
+                            }
+                            outw = outw && ymax <= kCuboidTol;
+                            inw = inw && ymin >= -kCuboidTol;
+                            const float L = ymax - ymin;
+                            A = fmaxf(A, L * n1f + n1(r1));
+                            B = fmaxf(B, L * wf + fabsf(r1.w));
+                        }
+                    }
+                    cert = outw ? 1 : ((inw && list) ? 2 : 0);   // (rooms are big: only the list can hold one)
+                    if (!(A < 1e30f && B < 1e30f)) cert = 0;
+                    if (cert) {
+                        atomicMax(&s_cubA, __float_as_int(A));
+                        atomicMax(&s_cubB, __float_as_int(B));
+                    }
+                }
                 if (list || 2 * npairs == g_hi - g_lo + 1) {
                     for (int a = g_lo; a <= g_hi; ++a)
                         if (!s_used[a]) s_order[out++] = (unsigned short)prim_at(a);
-                    if (list) out_meta[9] = npairs;
-                    else s_visit[i] = npairs;
+                    if (list) out_meta[9] = npairs | (cert << 8);
+                    else s_visit[i] = npairs | (cert << 8);
                 } else {
                     atomicAdd(&s_count, 1);
                 }
@@ -1673,6 +1800,10 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         if (s_count > 0 && i != kMaxPrims - 1 && g_hi > g_lo) {   // mixed scene: leave every leaf as it was
             for (int a = g_lo; a <= g_hi; ++a) s_order[a] = (unsigned short)(s_keys[a] & 0xFFFFFFFFu);
             s_visit[i] = 0;
+        }
+        if (i == 0) {
+            out_meta[11] = s_cubA;
+            out_meta[12] = s_cubB;
         }
         __syncthreads();
         if (i < n) {
