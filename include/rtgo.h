@@ -104,7 +104,8 @@ typedef struct rtgo_stats {
                                  scene's bounds instead of a traversal; always 0 for collect_stats launches */
     uint32_t launches_canonical; /* launches since rtgo_reset_stats that walked the canonical LBVH: collect_stats launches, and
                                     launches whose scene or eye reaches beyond 500 units (several times slower) */
-    uint32_t reserved;
+    uint32_t cuboid_groups;   /* scene property: groups of three rectangle pairs the build certified as the faces of one box or room
+                                 (tested by the fast walk's cuboid test); the up-front list's counts as one */
 } rtgo_stats;
 
 typedef struct rtgo_ctx rtgo_ctx;

@@ -56,6 +56,7 @@ struct rtgo_ctx {
     int fast_depth = 0;
     int n_small = 0;
     int n_fnodes = 0;             // nodes of the fast walk's tree
+    int cuboid_groups = 0;        // certified groups in the scene (leaves + the list's)
     int list_cub = 0;             // the up-front list starts with a certified box (1) / room (2): cuboid_range
     float cub_a = 0.0f, cub_b = 0.0f;   // its margin = kCuboidTol + K (cub_a R + cub_b), R = reach of the launch's rays
     int n_big_pairs = 0;
@@ -453,7 +454,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
                        (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight, std::getenv("RTGO_NO_CUBOID") ? 0 : 1);
     RTGO_HIP(c, hipGetLastError());
-    int meta[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int meta[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     c->tight.assign((size_t)n * 6, 0.0f);
     RTGO_HIP(c, hipMemcpyAsync(c->tight.data(), c->d_tight, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -464,6 +465,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     c->n_small = meta[2];
     c->n_big_pairs = meta[9] & 0xFF;
     c->list_cub = meta[9] >> 8;
+    c->cuboid_groups = meta[13] + (c->list_cub ? 1 : 0);
     std::memcpy(&c->cub_a, &meta[11], sizeof(float));
     std::memcpy(&c->cub_b, &meta[12], sizeof(float));
     c->n_fnodes = meta[10];
@@ -471,8 +473,8 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: the fast walk's tree has " + std::to_string(c->n_fnodes) + " nodes");
     std::memcpy(c->bounds, &meta[3], sizeof c->bounds);
     if (std::getenv("RTGO_DEBUG"))
-        std::fprintf(stderr, "rtgo_set_scene: %d primitives, %d in the fast walk's tree (%d nodes, depth %d), %d up front (%d pairs, cuboid certificate %d), margin coefficients %g %g, canonical LBVH depth %d\n",
-                     (int)n, c->n_small, c->n_fnodes, c->fast_depth, (int)n - c->n_small, c->n_big_pairs, c->list_cub, c->cub_a, c->cub_b, depth);
+        std::fprintf(stderr, "rtgo_set_scene: %d primitives, %d in the fast walk's tree (%d nodes, depth %d), %d up front (%d pairs, cuboid certificate %d), %d cuboid leaves, margin coefficients %g %g, canonical LBVH depth %d\n",
+                     (int)n, c->n_small, c->n_fnodes, c->fast_depth, (int)n - c->n_small, c->n_big_pairs, c->list_cub, meta[13], c->cub_a, c->cub_b, depth);
     if (depth > kStackDepth)
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
                                                std::to_string(kStackDepth) + ")");
@@ -1149,7 +1151,7 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     out->dbg_fast_tests = h[6];
     out->rays_culled = c->rays_culled;
     out->launches_canonical = c->launches_canonical;
-    out->reserved = 0;
+    out->cuboid_groups = (uint32_t)c->cuboid_groups;
     return RTGO_OK;
 }
 

@@ -552,7 +552,7 @@ __device__ __forceinline__ void leaf_range(Ptr fp, const float4* __restrict__ ld
 template <bool LIST, typename Ptr>
 __device__ __forceinline__ void cuboid_range(Ptr fp, const float4* __restrict__ lds, int first, float mu_out, float mu_in, v3 wo, v3 wd, float tmin, FastHit& best)
 {
-    float t[3], oy[3], dy[3];
+    float t[3], dy[3];
     bool front[3], ok[3], second[3];   // second: the pair's front-facing face is its second record
     bool both = false;
 #pragma unroll
@@ -566,10 +566,11 @@ __device__ __forceinline__ void cuboid_range(Ptr fp, const float4* __restrict__ 
         second[k] = !fa;
         const float4 r1 = lds[4 * (fa ? pos : pos + 1) + 1];   // (a per-lane read of the one row: cheaper than holding both for selects)
         dy[k] = fa ? dya : dyb;
-        oy[k] = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
-        t[k] = (0.0f - oy[k]) / dy[k];
+        const float oyk = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
+        t[k] = (0.0f - oyk) / dy[k];
         front[k] = fa != fb;
-        ok[k] = front[k] & (oy[k] > 0.0f);
+        ok[k] = front[k] & (oyk > 0.0f);
+        both = both | (front[k] & !(fabsf(t[k]) < 1e30f));   // (t overflowed: y_g below needs it finite; never seen, handled like `both`)
     }
     // rounding can let both faces of a pair through the sign test (the ray all but parallel to them): those lanes take the six
     // single tests and nothing else
@@ -580,7 +581,9 @@ __device__ __forceinline__ void cuboid_range(Ptr fp, const float4* __restrict__ 
         }
     }
     auto beyond = [&](int f, int g) {
-        const float y = oy[g] + t[f] * dy[g];
+        // y_g at the point where the ray meets f's plane: o.y_g + t_f d.y_g = d.y_g (t_f - t_g) up to 2^-24 of o.y_g (t_g = -o.y_g / d.y_g
+        // correctly rounded), which the margin covers -- and three registers fewer than keeping the o.y
+        const float y = dy[g] * (t[f] - t[g]);
         return front[g] & ((y > mu_out) | (y < mu_in));
     };
     bool s0 = ok[0] & !both & !beyond(0, 1) & !beyond(0, 2);
@@ -1695,12 +1698,13 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
             s_used[i] = 0;
             s_visit[i] = 0;   // (build_tree's arrival counters are no longer needed: pairs per node from here on)
         }
-        __shared__ int s_cubA, s_cubB;   // cuboid_range's margin coefficients (positive floats as bits: integer max = float max)
+        __shared__ int s_cubA, s_cubB, s_cubN;   // cuboid_range's margin coefficients (positive floats as bits: integer max = float max)
         if (i == 0) {
             out_meta[9] = 0;
             s_count = 0;   // leaves that do not pair up completely
             s_cubA = 0;
             s_cubB = 0;
+            s_cubN = 0;   // leaves certified as cuboids
         }
         __syncthreads();
         int g_lo = 0, g_hi = -1;
@@ -2033,11 +2037,14 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
             out_fnodes[2 * k + 0] = make_float4(t_box[k][0], t_box[k][1], t_box[k][2], __int_as_float(t_left[k]));
             out_fnodes[2 * k + 1] = make_float4(t_box[k][3], t_box[k][4], t_box[k][5], __int_as_float(t_right[k]));
             if (t_right[k] < 0) {   // a leaf: internal nodes above it = stack entries the walk can need on the way
+                if (((-t_right[k]) >> 20) != 0) atomicAdd(&s_cubN, 1);
                 int d = 0;
                 for (int q = t_parent[k]; q >= 0; q = t_parent[q]) ++d;
                 atomicMax(&s_depth, d);
             }
         }
+        __syncthreads();
+        if (i == 0) out_meta[13] = s_cubN;
     }
     __syncthreads();
     if (i == 0) {

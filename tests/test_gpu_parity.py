@@ -791,6 +791,113 @@ def test_rays_with_an_exactly_zero_direction_component(capi, oracle, name):
     ctx.close()
 
 
+def _cuboid_scene(oracle, W, H, variant):
+    """a closed room of six inward-facing walls (three pairs: the up-front list) holding two boxes of six rectangles each.
+    variant "good": both are cuboids; "wide_face": one face of the second box is 1.5 x too wide (it sticks out past its neighbours:
+    the point where a ray meets its plane can be beyond another face's plane and still inside the face); "sheared": the second box is
+    a parallelepiped (still the image of the unit cube); "inside_out": its six faces look into it"""
+    L = oracle.lib()
+    f = oracle.fptr
+
+    def mat(kind, *a):
+        out = np.zeros(16, dtype=np.float32)
+        getattr(L, "oracle_mat_" + kind)(*[np.float32(v) for v in a], f(out))
+        return out
+
+    def mul(*ms):
+        acc = ms[0]
+        for m in ms[1:]:
+            out = np.zeros(16, dtype=np.float32)
+            L.oracle_mat_mul(f(acc), f(m), f(out))
+            acc = out
+        return acc
+
+    hp = np.pi / 2
+    faces = [mul(mat("translate", 0, .5, 0)), mul(mat("translate", 0, -.5, 0), mat("rotate", np.pi, 1, 0, 0)),
+             mul(mat("translate", .5, 0, 0), mat("rotate", -hp, 0, 0, 1)), mul(mat("translate", -.5, 0, 0), mat("rotate", hp, 0, 0, 1)),
+             mul(mat("translate", 0, 0, .5), mat("rotate", hp, 1, 0, 0)), mul(mat("translate", 0, 0, -.5), mat("rotate", -hp, 1, 0, 0))]
+    types, M, mats = [], [], []
+
+    def add(m, kd=(0.7, 0.7, 0.7), kr=0.2, spec=1.0, Le=0.0):
+        types.append(2)
+        M.append(m)
+        mats.append([kd[0], kd[1], kd[2], kr, kr, kr, spec, Le, Le, Le])
+
+    add(mul(mat("translate", 0, -4, 0), mat("scale", 12, 1, 12)))
+    add(mul(mat("translate", 0, 4, 0), mat("rotate", np.pi, 1, 0, 0), mat("scale", 12, 1, 12)))
+    add(mul(mat("translate", -6, 0, 0), mat("rotate", -hp, 0, 0, 1), mat("scale", 8, 1, 12)), kd=(0.8, 0.2, 0.2))
+    add(mul(mat("translate", 6, 0, 0), mat("rotate", hp, 0, 0, 1), mat("scale", 8, 1, 12)), kd=(0.2, 0.8, 0.2))
+    add(mul(mat("translate", 0, 0, -6), mat("rotate", hp, 1, 0, 0), mat("scale", 12, 1, 8)))
+    add(mul(mat("translate", 0, 0, 6), mat("rotate", -hp, 1, 0, 0), mat("scale", 12, 1, 8)))
+    light = mul(mat("translate", 0, 3.9, 0), mat("rotate", np.pi, 1, 0, 0), mat("scale", 3, 1, 3))
+    add(light, kd=(0, 0, 0), kr=0, Le=6.0)
+    box_a = mul(mat("translate", -2.2, -2.5, 0.5), mat("rotate", 0.4, 0, 1, 0), mat("scale", 2.5, 3.0, 2.5))
+    box_b = mul(mat("translate", 2.0, -3.0, -1.0), mat("rotate", -0.3, 0, 1, 0), mat("scale", 2.0, 2.0, 2.0))
+    if variant == "sheared":
+        shear = np.eye(4, dtype=np.float32)
+        shear[0, 1] = 0.35
+        box_b = mul(box_b, shear.reshape(16).copy())
+    for face in faces:
+        add(mul(box_a, face), kd=(0.9, 0.8, 0.3))
+    for k, face in enumerate(faces):
+        m = mul(box_b, face)
+        if variant == "wide_face" and k == 0:
+            m = mul(m, mat("scale", 1.5, 1, 1))
+        if variant == "inside_out":
+            m = mul(m, mat("translate", 0, 0, 0), mat("rotate", np.pi, 1, 0, 0))   # the rectangle flipped in place
+        add(m, kd=(0.3, 0.5, 0.9), kr=0.5)
+    cam = oracle.scene_tables(oracle.scene("cornell", W, H))["cam"]
+    sc = oracle.scene_from_tables(np.array(types), np.stack(M), np.array(mats, dtype=np.float32),
+                                  np.stack([oracle.light_from_matrix(light, falloff=0.02)]), cam, (0.02, 0.02, 0.05))
+    return sc, oracle.scene_tables(sc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant,groups", [("good", 3), ("sheared", 3), ("wide_face", 2), ("inside_out", 2)])
+def test_cuboid_certificate_and_test(capi, oracle, variant, groups, monkeypatch):
+    """three rectangle pairs the build certifies as the faces of one box (leaves) or one room (the up-front list) go through the
+    fast walk's cuboid test (at most one of the three front-facing faces can be hit: the unit-square half of the test runs once).
+    The certificate is geometric -- every corner of every face on the inner side of the other pairs' planes -- so a box with a face
+    that sticks out, or one turned inside out, must not get it, a sheared one may; the pixels are the canonical walk's bit for bit
+    either way, and equal those of the pair-by-pair tests (RTGO_NO_CUBOID)"""
+    W, H, n = 128, 96, 3
+    sc, t = _cuboid_scene(oracle, W, H, variant)
+    prev = np.full((H, W, 4), 0.25, np.float32)
+    frames = {}
+    for knob in ("", "1"):
+        if knob:
+            monkeypatch.setenv("RTGO_NO_CUBOID", knob)
+        else:
+            monkeypatch.delenv("RTGO_NO_CUBOID", raising=False)
+        ctx = capi.Context(0)
+        ctx.set_scene(t["type"], t["M"], t["mat"], None)
+        ctx.set_camera(t["cam"][0:3], t["cam"][3:6], t["cam"][6:9], t["cam"][9:12])
+        ctx.set_background(t["bg"])
+        ctx.set_lights(t["lights"])
+        assert ctx.stats()["cuboid_groups"] == (0 if knob else groups), (variant, knob, ctx.stats()["cuboid_groups"])
+        for path in (True, False):
+            canon, cimg = gpu_render(capi, ctx, W, H, n, 2, path, stats=True, prev=prev)
+            fast, fimg = gpu_render(capi, ctx, W, H, n, 2, path, stats=False, prev=prev)
+            assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), "fast walk != canonical walk (%s, path=%s)" % (variant, path)
+            assert np.array_equal(fimg, cimg)
+            frames[(knob, path)] = (fast, fimg)
+        ctx.close()
+    for path in (True, False):
+        assert np.array_equal(frames[("", path)][0].view(np.uint32), frames[("1", path)][0].view(np.uint32))
+    racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 2, path=True, mode=1), accum_prev=prev)
+    assert_parity(frames[("", True)][0], racc, frames[("", True)][1], rimg, what="cuboid scene " + variant)
+
+
+def test_cuboid_certificates_of_the_reference_scenes(capi, oracle):
+    """cornell: the room and the two boxes; checkered: its 64 cubes; balls: the room"""
+    expect = {"cornell": 3, "balls": 1, "checkered": 64}
+    for name, want in expect.items():
+        sc, t, ctx = upload(capi, oracle, name, 64, 64)
+        got = ctx.stats()["cuboid_groups"]
+        assert got >= want, (name, got)
+        ctx.close()
+
+
 @pytest.mark.gpu
 def test_both_walks_agree_on_every_ray(tmp_path):
     """the -DRTGO_CMPWALK build of the library runs the fast walk next to the canonical one on EVERY ray of an instrumented launch
