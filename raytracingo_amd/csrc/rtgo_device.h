@@ -625,26 +625,11 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
 }
 
 
-__device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 const float4* __restrict__ g_fprims,
- unsigned int* __restrict__ s_stack, int bshift,
-                                                 int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, v3 o, v3 d, float tmin, float tmax, Hit& out,
-                                                 unsigned int& dbg_boxes, unsigned int& dbg_tests
-#ifdef RTGO_TIMELINE
-                                                 , unsigned long long& tl_big, unsigned long long& tl_tree
-#endif
-)
+// The fast walk in three parts (closest_hit_fast below runs them back to back; an experiment of round 2 ran the middle one in another
+// lane than the other two: profiles/r02f/README.md).  fast_list: the up-front list, which also gives the ray its first closest-hit bound.
+__device__ __forceinline__ void fast_list(const float4* __restrict__ s_fprims, const float4* __restrict__ g_fprims, int n_small, int n_prims, int n_big_pairs,
+                                          int list_cub, float cub_mu, v3 o, v3 d, float tmin, FastHit& best)
 {
-#ifdef RTGO_TIMELINE
-    const unsigned long long tl_s0 = wall_clock64();
-#endif
-    FastHit best;
-    best.t = tmax;
-    best.pos = -1;
-    best.orig = -1;
-    out.prim = -1;
-    out.t = tmax;
-    out.n = mk(0.0f, 0.0f, 0.0f);
     // the few "big" primitives (walls, floors; the whole scene when it is tiny) first.  The loop index is wave-uniform and
     // g_fprims is a read-only kernel argument, so the records arrive by scalar loads (s_load_dwordx4) into SGPRs: no LDS
     // traffic, no VGPRs for the matrices, and the loads of the next primitives overlap the tests of the current ones.
@@ -656,13 +641,12 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     } else {
         leaf_range<true>(g_fprims, s_fprims, n_small, n_prims - n_small, n_big_pairs, o, d, tmin, best);
     }
-#ifdef RTGO_FAST_COUNTERS
-    dbg_tests += (unsigned int)(n_prims - n_small);
-#endif
-#ifdef RTGO_TIMELINE
-    const unsigned long long tl_s1 = wall_clock64() + (best.pos == 12345 ? 1 : 0);
-    tl_big += tl_s1 - tl_s0;
-#endif
+}
+
+// fast_tree: the walk proper -- everything in the tree that can beat `best`
+__device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims, unsigned int* __restrict__ s_stack, int bshift,
+                                          int n_small, float cub_mu, v3 o, v3 d, float tmin, FastHit& best, unsigned int& dbg_boxes, unsigned int& dbg_tests)
+{
     // 1/d for the slab tests.  A direction component that is exactly zero is not rare: the hemisphere sample has sin(phi) = 0
     // whenever its random number is 0 (one ray in 2^24 per bounce, a few per 1080p frame), and cameras can be axis-aligned.
     // rcp(0) = inf would turn fma(b, 1/d, -o/d) into inf - inf = NaN on one side of the origin and -inf on the other, and a
@@ -730,9 +714,14 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
             have = pop();
         }
     }
-#ifdef RTGO_TIMELINE
-    tl_tree += wall_clock64() + (best.pos == 12345 ? 1 : 0) - tl_s1;
-#endif
+}
+
+// fast_winner: the closest hit's record for the closest-hit program (t, SBT index, world normal)
+__device__ __forceinline__ bool fast_winner(const float4* __restrict__ s_fprims, v3 o, v3 d, float tmax, const FastHit& best, Hit& out)
+{
+    out.prim = -1;
+    out.t = tmax;
+    out.n = mk(0.0f, 0.0f, 0.0f);
     if (best.pos < 0) return false;
     const int wpos = best.pos & (kFlat - 1);
     const bool flat = (best.pos & kFlat) != 0;
@@ -751,6 +740,38 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     out.n = xf_normal(r0, r1, r2, nobj);
     out.prim = best.orig;
     return true;
+}
+
+__device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
+                                                 const float4* __restrict__ g_fprims,
+ unsigned int* __restrict__ s_stack, int bshift,
+                                                 int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, v3 o, v3 d, float tmin, float tmax, Hit& out,
+                                                 unsigned int& dbg_boxes, unsigned int& dbg_tests
+#ifdef RTGO_TIMELINE
+                                                 , unsigned long long& tl_big, unsigned long long& tl_tree
+#endif
+)
+{
+#ifdef RTGO_TIMELINE
+    const unsigned long long tl_s0 = wall_clock64();
+#endif
+    FastHit best;
+    best.t = tmax;
+    best.pos = -1;
+    best.orig = -1;
+    fast_list(s_fprims, g_fprims, n_small, n_prims, n_big_pairs, list_cub, cub_mu, o, d, tmin, best);
+#ifdef RTGO_FAST_COUNTERS
+    dbg_tests += (unsigned int)(n_prims - n_small);
+#endif
+#ifdef RTGO_TIMELINE
+    const unsigned long long tl_s1 = wall_clock64() + (best.pos == 12345 ? 1 : 0);
+    tl_big += tl_s1 - tl_s0;
+#endif
+    fast_tree(s_fnodes, s_fprims, s_stack, bshift, n_small, cub_mu, o, d, tmin, best, dbg_boxes, dbg_tests);
+#ifdef RTGO_TIMELINE
+    tl_tree += wall_clock64() + (best.pos == 12345 ? 1 : 0) - tl_s1;
+#endif
+    return fast_winner(s_fprims, o, d, tmax, best, out);
 }
 
 // acos(pow(base, expo)) with both steps in f64, each rounded to float like the reference's float calls.  Kept out of line:
