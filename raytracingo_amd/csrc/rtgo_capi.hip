@@ -742,7 +742,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.fprims = c->d_fprims;
     p.n_small = c->n_small;
     p.n_big_pairs = c->n_big_pairs;
-    p.stack_depth = canon ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1);
+    p.stack_depth = canon ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1) + 1;   // (+1: fast_tree writes the slot past the top before it knows whether it pushes)
     p.lights = c->d_lights;
     p.accum = c->d_accum;
     p.image = c->d_image;
