@@ -845,8 +845,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (grid > need) grid = need;
 
     if (std::getenv("RTGO_DEBUG"))
-        std::fprintf(stderr, "rtgo_launch: %s walk%s, grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d\n",
-                     canon ? "canonical" : "fast", (canon && !stats) ? " (scene or eye beyond 500 units)" : "", grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth);
+        std::fprintf(stderr, "rtgo_launch: %s walk%s, grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d, cuboid margin %g\n",
+                     canon ? "canonical" : "fast", (canon && !stats) ? " (scene or eye beyond 500 units)" : "", grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth, p.cub_mu);
 #ifdef RTGO_TIMELINE
     c->timeline_waves = grid * (unsigned int)(block / 64);
     if (c->timeline_waves > 16384) return fail(c, RTGO_E_UNSUPPORTED, "timeline buffer too small");

@@ -837,6 +837,8 @@ def _cuboid_scene(oracle, W, H, variant):
         shear = np.eye(4, dtype=np.float32)
         shear[0, 1] = 0.35
         box_b = mul(box_b, shear.reshape(16).copy())
+    if variant == "tiny_far":
+        box_b = mul(mat("translate", 2.0, -3.9, -1.0), mat("rotate", -0.3, 0, 1, 0), mat("scale", 0.12, 0.12, 0.12))
     for face in faces:
         add(mul(box_a, face), kd=(0.9, 0.8, 0.3))
     for k, face in enumerate(faces):
@@ -846,14 +848,18 @@ def _cuboid_scene(oracle, W, H, variant):
         if variant == "inside_out":
             m = mul(m, mat("translate", 0, 0, 0), mat("rotate", np.pi, 1, 0, 0))   # the rectangle flipped in place
         add(m, kd=(0.3, 0.5, 0.9), kr=0.5)
-    cam = oracle.scene_tables(oracle.scene("cornell", W, H))["cam"]
+    cam = np.array(oracle.scene_tables(oracle.scene("cornell", W, H))["cam"], dtype=np.float32).copy()
+    if variant in ("far", "tiny_far"):
+        # the same view from 12 x the distance (eye 168 units out, still the fast walk's domain): the margin of the cuboid test grows with
+        # the rays' reach -- a fat margin for "far", beyond the 0.02 at which the launch stops using the test for "tiny_far"
+        cam[0:12] *= 12.0
     sc = oracle.scene_from_tables(np.array(types), np.stack(M), np.array(mats, dtype=np.float32),
                                   np.stack([oracle.light_from_matrix(light, falloff=0.02)]), cam, (0.02, 0.02, 0.05))
     return sc, oracle.scene_tables(sc)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant,groups", [("good", 3), ("sheared", 3), ("wide_face", 2), ("inside_out", 2)])
+@pytest.mark.parametrize("variant,groups", [("good", 3), ("sheared", 3), ("wide_face", 2), ("inside_out", 2), ("far", 3), ("tiny_far", 3)])
 def test_cuboid_certificate_and_test(capi, oracle, variant, groups, monkeypatch):
     """three rectangle pairs the build certifies as the faces of one box (leaves) or one room (the up-front list) go through the
     fast walk's cuboid test (at most one of the three front-facing faces can be hit: the unit-square half of the test runs once).
@@ -881,6 +887,7 @@ def test_cuboid_certificate_and_test(capi, oracle, variant, groups, monkeypatch)
             assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)), "fast walk != canonical walk (%s, path=%s)" % (variant, path)
             assert np.array_equal(fimg, cimg)
             frames[(knob, path)] = (fast, fimg)
+        assert ctx.stats()["launches_canonical"] == 2, "the timed launches must have taken the fast walk"
         ctx.close()
     for path in (True, False):
         assert np.array_equal(frames[("", path)][0].view(np.uint32), frames[("1", path)][0].view(np.uint32))
