@@ -327,6 +327,7 @@ int rtgo_create(int device, rtgo_ctx** out)
         if (err == hipSuccess) err = hipFuncSetAttribute((const void*)e.fn, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
     // (the build kernel holds ~58 KB of static LDS; its dynamic part is the fast walk's tree under construction)
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildDynLds);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::sah_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kAllInL2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kRecordsInLds>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kAllInLds>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -956,7 +957,7 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     RTGO_HIP(c, hipMalloc(&c->w_tris, (size_t)n_triangles * 3 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->w_qrecs, (size_t)n_triangles * 2 * sizeof(uint4)));
     RTGO_HIP(c, hipMalloc(&c->w_tidx, (size_t)n_triangles * sizeof(uint2)));
-    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(6 * n_triangles + 16) * sizeof(int)));   // parent [2n-1], visit, first, count, record [n each], meta
+    RTGO_HIP(c, hipMalloc(&c->w_scratch, (size_t)(6 * n_triangles + 16 + 32 * n_triangles) * sizeof(int)));   // parent [2n-1], visit, first, count, record [n each], meta, sah_kernel's 32 n
     int* parent = c->w_scratch;
     int* visit = parent + (2 * n_triangles - 1);
     int* first_of = visit + n_triangles;
@@ -966,6 +967,13 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), 0, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
                        parent, visit, first_of, count_of, rec_of, c->w_recs, c->w_tris, c->w_qrecs, c->w_tidx, meta);
     RTGO_HIP(c, hipGetLastError());
+    if (!std::getenv("RTGO_WHITTED_NO_SAH")) {
+        // the records over the same leaves, rebuilt top-down with the surface-area heuristic (leaf boxes, links, order arrays in LDS)
+        const size_t sah_lds = (size_t)n_triangles * (6 * sizeof(float) + sizeof(int) + 2 * sizeof(short) + 1) + 16;
+        hipLaunchKernelGGL(whitted::sah_kernel, dim3(1), dim3(whitted::kBuildThreads), sah_lds, c->stream, (int)n_triangles, (const float4*)c->w_nodes, (const int*)parent,
+                           (const int*)first_of, (const int*)count_of, meta + 16, c->w_recs, c->w_qrecs, meta);
+        RTGO_HIP(c, hipGetLastError());
+    }
     int m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(m, meta, sizeof m, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));

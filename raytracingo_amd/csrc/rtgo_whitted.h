@@ -775,5 +775,211 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The walk's records rebuilt over the same leaves with the surface-area heuristic (second session of round 2).  build_kernel's
+// Morton hierarchy forms the leaves (subtrees of at most kLeafTris triangles: neighbours in Morton order, contiguous in `tris`);
+// above them bit prefixes know nothing of box areas, and any tree over the same leaves returns the same hits, so the topology is
+// rebuilt top-down like the analytic path's (rtgo_device.h, build_kernel): every node is split where
+// A(left) * T(left) + A(right) * T(right) is smallest over the three axes and every position of its leaves sorted by centroid
+// (T = triangles).  One workgroup: all threads walk one task queue together -- a rank sort per axis in parallel, the sweep by one
+// thread.  What sets the whitted launch is one wave's serial walk over the finely tessellated part: fewer steps there.
+// Overwrites recs / qrecs and out_meta[1] (records), [2] (stack entries); scratch: 32 n ints.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBuildThreads) void sah_kernel(int n, const float4* __restrict__ nodes, const int* __restrict__ parent, const int* __restrict__ first_of,
+                                                            const int* __restrict__ count_of, int* __restrict__ scratch, float4* __restrict__ recs,
+                                                            uint4* __restrict__ qrecs, int* __restrict__ out_meta)
+{
+    if (n <= kLeafTris) return;   // the mesh is one leaf: no records
+    extern __shared__ __attribute__((aligned(16))) unsigned char sah_dyn[];
+    float (*u_box)[6] = reinterpret_cast<float (*)[6]>(sah_dyn);      // [n] leaf boxes
+    int* u_link = reinterpret_cast<int*>(u_box + n);                  // [n] the leaf's link in the walk's records
+    short* perm = reinterpret_cast<short*>(u_link + n);               // [n] leaves in the current task order
+    short* tmp = perm + n;                                            // [n]
+    unsigned char* u_w = reinterpret_cast<unsigned char*>(tmp + n);   // [n] triangles of the leaf
+    __shared__ int s_U, s_qtail, s_count, s_best_axis, s_best_pos, s_wdepth, s_nrec;
+    // global scratch (one thread group, barriers order it)
+    int* t_left = scratch;               // [2n] first child / the leaf's link
+    int* t_right = t_left + 2 * n;       // [2n] second child, -1: a leaf
+    int* t_parent = t_right + 2 * n;     // [2n]
+    int* tq_node = t_parent + 2 * n;     // [2n] task queue
+    int* tq_lo = tq_node + 2 * n;
+    int* tq_hi = tq_lo + 2 * n;
+    float* t_box = reinterpret_cast<float*>(tq_hi + 2 * n);   // [2n][6]
+    int* start = reinterpret_cast<int*>(t_box + 12 * n);      // [n] node of the leaf that starts at a Morton position, -1: none
+    int* rec_of = start + n;                                  // [2n]
+    float* sfx = reinterpret_cast<float*>(rec_of + 2 * n);    // [n][2] suffix area and triangles of the sweep
+    const int tid = threadIdx.x, leaf0 = n - 1;
+    for (int pos = tid; pos < n; pos += kBuildThreads) start[pos] = -1;
+    __syncthreads();
+    for (int k = tid; k < 2 * n - 1; k += kBuildThreads) {
+        const int cnt = k >= leaf0 ? 1 : count_of[k];
+        const bool is_leaf = cnt <= kLeafTris && k != 0 && count_of[parent[k]] > kLeafTris;
+        if (is_leaf) start[k >= leaf0 ? k - leaf0 : first_of[k]] = k;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int U = 0;
+        for (int pos = 0; pos < n; ++pos)
+            if (start[pos] >= 0) rec_of[U++] = start[pos];   // (rec_of borrowed: leaf u's node)
+        s_U = U;
+        s_wdepth = 0;
+    }
+    __syncthreads();
+    const int U = s_U;
+    for (int u = tid; u < U; u += kBuildThreads) {
+        const int k = rec_of[u];
+        const float4 b0 = nodes[2 * k], b1 = nodes[2 * k + 1];
+        u_box[u][0] = b0.x; u_box[u][1] = b0.y; u_box[u][2] = b0.z;
+        u_box[u][3] = b1.x; u_box[u][4] = b1.y; u_box[u][5] = b1.z;
+        const int first = k >= leaf0 ? k - leaf0 : first_of[k], cnt = k >= leaf0 ? 1 : count_of[k];
+        u_link[u] = -1 - (first | ((cnt - 1) << 12));
+        u_w[u] = (unsigned char)cnt;
+        perm[u] = (short)u;
+    }
+    if (tid == 0) {
+        tq_node[0] = 0; tq_lo[0] = 0; tq_hi[0] = U;
+        s_qtail = 1;
+        s_count = 1;
+        t_parent[0] = -1;
+    }
+    __syncthreads();
+    for (int qi = 0; qi < 2 * n; ++qi) {
+        __syncthreads();
+        if (qi >= s_qtail) break;   // (uniform: every thread reads the same word after the barrier)
+        const int lo = tq_lo[qi], hi = tq_hi[qi], node = tq_node[qi], m = hi - lo;
+        if (m == 1) {
+            if (tid == 0) {
+                const int u = perm[lo];
+                for (int c = 0; c < 6; ++c) t_box[6 * node + c] = u_box[u][c];
+                t_left[node] = u_link[u];
+                t_right[node] = -1;
+            }
+            continue;
+        }
+        if (tid == 0) {
+            s_best_axis = -1;
+            s_best_pos = m / 2;
+        }
+        float best_cost = INFINITY;   // (thread 0's)
+        for (int pass = 0; pass < 4; ++pass) {
+            // passes 0..2: try axis `pass`; pass 3: put the range back in the order of the best axis
+            __syncthreads();
+            const int axis = pass < 3 ? pass : s_best_axis;
+            if (pass == 3 && (axis < 0 || axis == 2)) break;   // (uniform) no finite cost at all, or already in z order
+            for (int e = tid; e < m; e += kBuildThreads) {
+                const int me = perm[lo + e];
+                const float key = u_box[me][axis] + u_box[me][3 + axis];
+                int rank = 0;
+                for (int j = 0; j < m; ++j) {
+                    const int other = perm[lo + j];
+                    const float kj = u_box[other][axis] + u_box[other][3 + axis];
+                    rank += (kj < key || (kj == key && other < me)) ? 1 : 0;
+                }
+                tmp[lo + rank] = (short)me;
+            }
+            __syncthreads();
+            for (int e = tid; e < m; e += kBuildThreads) perm[lo + e] = tmp[lo + e];
+            __syncthreads();
+            if (pass < 3 && tid == 0) {
+                float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int w = 0;
+                for (int j = m - 1; j >= 1; --j) {
+                    const int u = perm[lo + j];
+                    for (int c = 0; c < 3; ++c) {
+                        b[c] = fminf(b[c], u_box[u][c]);
+                        b[3 + c] = fmaxf(b[3 + c], u_box[u][3 + c]);
+                    }
+                    w += u_w[u];
+                    const float ex = b[3] - b[0], ey = b[4] - b[1], ez = b[5] - b[2];
+                    sfx[2 * j + 0] = ex * ey + ey * ez + ez * ex;
+                    sfx[2 * j + 1] = (float)w;
+                }
+                float a[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int wl = 0;
+                for (int j = 1; j < m; ++j) {   // left = [0, j), right = [j, m)
+                    const int u = perm[lo + j - 1];
+                    for (int c = 0; c < 3; ++c) {
+                        a[c] = fminf(a[c], u_box[u][c]);
+                        a[3 + c] = fmaxf(a[3 + c], u_box[u][3 + c]);
+                    }
+                    wl += u_w[u];
+                    const float ex = a[3] - a[0], ey = a[4] - a[1], ez = a[5] - a[2];
+                    const float cost = (ex * ey + ey * ez + ez * ex) * (float)wl + sfx[2 * j] * sfx[2 * j + 1];
+                    if (cost < best_cost) {
+                        best_cost = cost;
+                        s_best_axis = pass;
+                        s_best_pos = j;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float b[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int j = lo; j < hi; ++j) {
+                const int u = perm[j];
+                for (int c = 0; c < 3; ++c) {
+                    b[c] = fminf(b[c], u_box[u][c]);
+                    b[3 + c] = fmaxf(b[3 + c], u_box[u][3 + c]);
+                }
+            }
+            const int cl = s_count, cr = s_count + 1;
+            s_count += 2;
+            for (int c = 0; c < 6; ++c) t_box[6 * node + c] = b[c];
+            t_left[node] = cl;
+            t_right[node] = cr;
+            t_parent[cl] = node;
+            t_parent[cr] = node;
+            const int mid = lo + s_best_pos;
+            const int t = s_qtail;
+            tq_node[t] = cl; tq_lo[t] = lo; tq_hi[t] = mid;
+            tq_node[t + 1] = cr; tq_lo[t + 1] = mid; tq_hi[t + 1] = hi;
+            s_qtail = t + 2;
+        }
+    }
+    __syncthreads();
+    const int n_nodes = s_count;
+    if (tid == 0) {
+        int r = 0;
+        for (int k = 0; k < n_nodes; ++k) rec_of[k] = t_right[k] >= 0 ? r++ : -1;   // (the root is node 0 and record 0)
+        s_nrec = r;
+    }
+    __syncthreads();
+    float glo[3], gstep[3];
+    for (int a = 0; a < 3; ++a) {
+        glo[a] = __int_as_float(out_meta[3 + a]);
+        gstep[a] = __int_as_float(out_meta[6 + a]);
+    }
+    for (int k = tid; k < n_nodes; k += kBuildThreads) {
+        const int r = rec_of[k];
+        if (r < 0) continue;
+        const int L = t_left[k], R = t_right[k];
+        const int linkL = t_right[L] >= 0 ? rec_of[L] : t_left[L], linkR = t_right[R] >= 0 ? rec_of[R] : t_left[R];
+        const float* a = t_box + 6 * L;
+        const float* b = t_box + 6 * R;
+        recs[4 * r + 0] = make_float4(a[0], a[1], a[2], __int_as_float(linkL));
+        recs[4 * r + 1] = make_float4(a[3], a[4], a[5], 0.0f);
+        recs[4 * r + 2] = make_float4(b[0], b[1], b[2], __int_as_float(linkR));
+        recs[4 * r + 3] = make_float4(b[3], b[4], b[5], 0.0f);
+        auto cell = [&](float v, int ax, bool up) -> unsigned int {
+            const float c = (v - glo[ax]) / gstep[ax];
+            const float q = up ? ceilf(c) + 1.0f : floorf(c) - 1.0f;
+            return (unsigned int)fminf(fmaxf(q, 0.0f), 65535.0f);
+        };
+        qrecs[2 * r + 0] = make_uint4(cell(a[0], 0, false) | (cell(a[3], 0, true) << 16), cell(a[1], 1, false) | (cell(a[4], 1, true) << 16),
+                                      cell(a[2], 2, false) | (cell(a[5], 2, true) << 16), (unsigned int)linkL);
+        qrecs[2 * r + 1] = make_uint4(cell(b[0], 0, false) | (cell(b[3], 0, true) << 16), cell(b[1], 1, false) | (cell(b[4], 1, true) << 16),
+                                      cell(b[2], 2, false) | (cell(b[5], 2, true) << 16), (unsigned int)linkR);
+        int dd = 1;   // stack entries a walk can hold below this record: one per record on the way down, its own included
+        for (int q = t_parent[k]; q >= 0; q = t_parent[q]) ++dd;
+        atomicMax(&s_wdepth, dd);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        out_meta[1] = s_nrec;
+        out_meta[2] = s_wdepth;
+    }
+}
+
 }  // namespace whitted
 }  // namespace rtgo

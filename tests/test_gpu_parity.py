@@ -1059,6 +1059,36 @@ def test_whitted_the_three_residency_modes_agree(capi, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_whitted_surface_area_tree_and_morton_tree_agree(capi, oracle, monkeypatch):
+    """rtgo_whitted_set_mesh rebuilds the walk's records over the Morton hierarchy's leaves with the surface-area heuristic
+    (sah_kernel); RTGO_WHITTED_NO_SAH keeps the Morton topology.  Any tree over the same leaves returns the same hits: the frames are
+    bitwise one frame in every residency mode, for a mesh of a few leaves and for the largest mesh the build takes"""
+    import whitted_scene
+    W, H = 128, 80
+    cam = whitted_scene.camera(oracle, W, H)
+    for n_lat, n_lon in ((2, 3), (6, 8), (43, 48)):   # 20, 94 and 4046 triangles (the build takes 4096)
+        mesh = whitted_scene.build(n_lat=n_lat, n_lon=n_lon)
+        frames = []
+        for no_sah in (False, True):
+            for mode in ("2", "0"):
+                monkeypatch.setenv("RTGO_WHITTED_MODE", mode)
+                if no_sah:
+                    monkeypatch.setenv("RTGO_WHITTED_NO_SAH", "1")
+                else:
+                    monkeypatch.delenv("RTGO_WHITTED_NO_SAH", raising=False)
+                ctx = _whitted_ctx(capi, mesh, cam, W, H)
+                ctx.reset_stats()
+                for sf in range(2):
+                    ctx.whitted_launch(W, H, sf)
+                ctx.sync()
+                frames.append((ctx.read_accum(H, W), ctx.read_image(H, W), ctx.stats()["rays_total"]))
+                ctx.close()
+        for acc, img, rays in frames[1:]:
+            assert np.array_equal(acc.view(np.uint32), frames[0][0].view(np.uint32)) and np.array_equal(img, frames[0][1]) and rays == frames[0][2], (n_lat, n_lon)
+    monkeypatch.delenv("RTGO_WHITTED_NO_SAH", raising=False)
+
+
+@pytest.mark.gpu
 def test_whitted_against_the_committed_fixture(capi):
     """tests/golden/oracle_whitted.npz: the GPU against stored oracle output (no oracle run needed)"""
     import whitted_scene
