@@ -777,7 +777,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
     const int fast_nodes = c->n_fnodes;
     const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims) * sizeof(float4) +
-                             (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float);   // + the raygen constants
+                             (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float) +   // + the raygen constants
+                             (size_t)(nn < (uint32_t)kSampleTab ? nn : (uint32_t)kSampleTab) * sizeof(uint4);   // + the per-sample start table
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
     size_t lds = 0;
     // Waves per SIMD the kernel variant is compiled for: 4 (<= 128 VGPRs) or 5 (<= 96, level records in LDS; 1-2 spilled dwords).

@@ -22,7 +22,10 @@ constexpr int kMaxTriangles = 4096;   // one workgroup sorts the Morton keys in 
 constexpr int kBuildThreads = 1024;
 constexpr int kStack = 32;            // bound on the depth of the Karras hierarchy the build accepts (fit passes, parent chains)
 constexpr int kRenderBlock = 1024;    // one workgroup per CU shares one LDS copy of the records
-constexpr int kLeafTris = 4;          // a subtree of at most this many triangles is one leaf of the walk
+#ifndef RTGO_LEAF_TRIS
+#define RTGO_LEAF_TRIS 4
+#endif
+constexpr int kLeafTris = RTGO_LEAF_TRIS;          // a subtree of at most this many triangles is one leaf of the walk
 constexpr int kMaxWalkDepth = 40;
 // where the walk reads from: records and triangles in L2 / fp32 records in LDS, triangles in L2 / quantised records, vertices and
 // triangle indices all in LDS
