@@ -105,10 +105,50 @@ __device__ __forceinline__ v3 vcross(v3 a, v3 b)                                
 {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-__device__ __forceinline__ float vlength(v3 v) { return sqrtf(vdot(v, v)); }  // vec_math.h:535-538
+// Correctly rounded a / b and sqrt(x) as the compiler's own expansions compute them, without the range plumbing around them.
+// hipcc expands an IEEE f32 division into v_div_scale x 2, v_rcp, six v_fma / v_mul, v_div_fmas, v_div_fixup (12 instructions): the
+// scale / fmas / fixup steps only act when an operand is zero, infinite, NaN or subnormal, when |a / b| leaves [2^-126, 2^96) or when
+// |a| < 2^-103 (V_DIV_SCALE_F32's rules); otherwise they pass their operands through and the quotient is the value of the eight steps
+// below, bit for bit.  Likewise sqrtf: v_sqrt_f32 and two residual tests against the neighbouring floats are the correctly rounded
+// root for normal x in [2^-96, inf); the other nine instructions rescale subnormal inputs and pass 0 / inf / NaN through.
+// Where these run (ray parameters t = -o.y / d.y of front-facing planes with o.y > 0, sphere roots, lengths of directions and
+// normals) a quotient outside those ranges is rejected by the comparisons that follow whatever its value (|t| >= 2^95 or < 2^-126
+// against 1e-4 < t < tmax <= 1e16), and operands are float combinations of scene coordinates (|.| <= 500, granularity ~1e-7 of
+// them): zero, or nowhere near 2^-103.  The canonical walk keeps the plain operators, so every fast == canonical test -- the suite,
+// tools/cmp_walks.py ray by ray, the fuzzers -- holds the lean forms to IEEE on every ray traced.  -DRTGO_IEEE_OPS: plain operators.
+__device__ __forceinline__ float div_cr(float a, float b)
+{
+#ifdef RTGO_IEEE_OPS
+    return a / b;
+#else
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = fmaf(-b, y0, 1.0f);
+    const float y1 = fmaf(e, y0, y0);
+    const float q0 = a * y1;
+    const float r0 = fmaf(-b, q0, a);
+    const float q1 = fmaf(r0, y1, q0);
+    const float r1 = fmaf(-b, q1, a);
+    return fmaf(r1, y1, q1);
+#endif
+}
+__device__ __forceinline__ float sqrt_cr(float x)
+{
+#ifdef RTGO_IEEE_OPS
+    return sqrtf(x);
+#else
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sdn = __uint_as_float(__float_as_uint(s) - 1u), sup = __uint_as_float(__float_as_uint(s) + 1u);
+    const float vdn = fmaf(-sdn, s, x), vup = fmaf(-sup, s, x);
+    float r = vdn <= 0.0f ? sdn : s;
+    r = vup > 0.0f ? sup : r;
+    return r;
+#endif
+}
+
+__device__ __forceinline__ float vlength(v3 v) { return sqrt_cr(vdot(v, v)); }  // vec_math.h:535-538
 __device__ __forceinline__ v3 vnormalize(v3 v)                               // vec_math.h:541-545
 {
-    float invLen = 1.0f / sqrtf(vdot(v, v));
+    float invLen = div_cr(1.0f, sqrt_cr(vdot(v, v)));
     return vscale(v, invLen);
 }
 
@@ -417,7 +457,7 @@ __device__ __forceinline__ void rect_commit(Ptr rec, const float4 r1, float dy, 
 {
     const float oy = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
     // oy > 0 with d.y < 0 is the only way to t > 0 (so d.y != 0 and t > 1e-4 can hold); lanes that fail carry garbage in t
-    const float t = (0.0f - oy) / dy;
+    const float t = div_cr(0.0f - oy, dy);
     const bool c = facing & (oy > 0.0f) & (t > 0.0001f) & closer(t, orig, tmin, best);
     rect_finish(rec, t, c, pos, orig, wo, wd, best);
 }
@@ -442,8 +482,8 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
         const float c = vdot(o, o) - 1.0f;
         const float discr = b * b - 4.0f * a * c;
         if (discr > 0.0f) {
-            const float sdiscr = sqrtf(discr);
-            const float t = (-b - sdiscr) / (2.0f * a);
+            const float sdiscr = sqrt_cr(discr);
+            const float t = div_cr(-b - sdiscr, 2.0f * a);
             if (t > 0.0001f && closer(t, orig, tmin, best)) {
                 best.t = t;
                 best.pos = pos;
@@ -456,9 +496,9 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
         const float c = o.x * o.x + o.z * o.z - 1.0f;
         const float discr = b * b - 4.0f * a * c;
         if (discr > 0.001f) {
-            const float sdiscr = sqrtf(discr);
-            const float t0 = (-b + sdiscr) / (2.0f * a);
-            const float t1 = (-b - sdiscr) / (2.0f * a);
+            const float sdiscr = sqrt_cr(discr);
+            const float t0 = div_cr(-b + sdiscr, 2.0f * a);
+            const float t1 = div_cr(-b - sdiscr, 2.0f * a);
             float t = 1e16f;
             bool valid = false;
             if (t0 > 0.001f) {
@@ -484,7 +524,7 @@ __device__ __forceinline__ void leaf_test(Ptr s_fprims, int pos, v3 wo, v3 wd, f
     } else {  // disk
         const float divisor = d.y;
         if (!(divisor > 0.0f - 0.01f && divisor < 0.0f + 0.01f)) {
-            const float t = (-o.y) / divisor;
+            const float t = div_cr(-o.y, divisor);
             if (t > 0.0001f && closer(t, orig, tmin, best)) {
                 const v3 p = vadd(o, vscale(d, t));
                 if (vdot(p, p) < 1.0f) {
@@ -568,7 +608,7 @@ __device__ __forceinline__ void cuboid_range(Ptr fp, const float4* __restrict__ 
         const float4 r1 = lds[4 * (fa ? pos : pos + 1) + 1];   // (a per-lane read of the one row: cheaper than holding both for selects)
         dy[k] = fa ? dya : dyb;
         const float oyk = r1.x * wo.x + r1.y * wo.y + r1.z * wo.z + r1.w;
-        t[k] = (0.0f - oyk) / dy[k];
+        t[k] = div_cr(0.0f - oyk, dy[k]);
         front[k] = fa != fb;
         ok[k] = front[k] & (oyk > 0.0f);
         both = both | (front[k] & !(fabsf(t[k]) < 1e30f));   // (t overflowed: y_g below needs it finite; never seen, handled like `both`)
@@ -792,7 +832,7 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
     const v3 Y = vnormalize(direction);
     const v3 X = vnormalize(mk(Y.y - Y.z, -Y.x, Y.x));
     const v3 Z = vcross(Y, X);
-    const float expo = 1.f / (coefficient + 1.f);
+    const float expo = div_cr(1.f, coefficient + 1.f);
     do {
         const float r1 = rnd(seed);
         const float r2 = rnd(seed);
@@ -805,7 +845,7 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
         } else if (expo == 0.5f) {
             // specularity 1 (every cornell surface in distributed mode): pow(x, 1/2) is sqrt(x), which IS correctly rounded on
             // the device, and the lobe is as wide as the diffuse one, so float acosf is as benign here as it is there
-            theta = acosf(sqrtf(base));
+            theta = acosf(sqrt_cr(base));
         } else {
             // glossy lobe: acos(pow(x, 1/(coef+1))) sits at the ill-conditioned end of acos (argument within 1e-4 of 1),
             // where one ulp of pow moves theta by ~1e-3 relative.  Evaluate both in f64 and round, which reproduces a

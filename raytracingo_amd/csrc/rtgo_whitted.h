@@ -97,7 +97,7 @@ __device__ __forceinline__ bool tri_intersect(v3 p0, v3 p1, v3 p2, v3 o, v3 d, f
     const v3 pv = vcross(d, e2);
     const float det = vdot(e1, pv);
     if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
+    const float inv = div_cr(1.0f, det);   // (rtgo_device.h: the compiler's own correctly rounded steps; |det| is 0 or far above 2^-96 for triangles of any sane size)
     const v3 tv = vsub(o, p0);
     const float u = vdot(tv, pv) * inv;
     if (u < 0.0f || u > 1.0f) return false;
@@ -230,8 +230,8 @@ __device__ __forceinline__ v3 schlick(v3 spec, float VdotH)
 __device__ __forceinline__ float vis(float NdotL, float NdotV, float alpha)
 {
     const float a2 = alpha * alpha;
-    const float g0 = NdotL * sqrtf(NdotV * NdotV * (1.0f - a2) + a2);
-    const float g1 = NdotV * sqrtf(NdotL * NdotL * (1.0f - a2) + a2);
+    const float g0 = NdotL * sqrt_cr(NdotV * NdotV * (1.0f - a2) + a2);
+    const float g1 = NdotV * sqrt_cr(NdotL * NdotL * (1.0f - a2) + a2);
     return 2.0f * NdotL * NdotV / (g0 + g1);
 }
 __device__ __forceinline__ float ggx_normal(float NdotH, float alpha)
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
                 jx = rnd(seed) - 0.5f;   // x first (source order)
                 jy = rnd(seed) - 0.5f;
             }
-            const float dx = 2.0f * (((float)x + jx) / (float)p.width) - 1.0f;
-            const float dy = 2.0f * (((float)y + jy) / (float)p.height) - 1.0f;
+            const float dx = 2.0f * div_cr((float)x + jx, (float)p.width) - 1.0f;
+            const float dy = 2.0f * div_cr((float)y + jy, (float)p.height) - 1.0f;
             const v3 rd = vnormalize(vadd(vadd(vscale(p.U, dx), vscale(p.V, dy)), p.W));
             const v3 ro = p.eye;
             v3 result = p.miss;   // __miss__constant_radiance, :243-246

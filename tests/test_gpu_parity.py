@@ -906,6 +906,23 @@ def test_cuboid_certificates_of_the_reference_scenes(capi, oracle):
 
 
 @pytest.mark.gpu
+def test_lean_ops_are_ieee(tmp_path):
+    """div_cr / sqrt_cr (rtgo_device.h: the compiler's own correctly rounded division and square root without the range plumbing around
+    them) against the plain operators on the device, bit for bit, over 2^30 operand pairs per range drawn log-uniformly from the ranges
+    the kernels feed them: tools/lean_ops_probe.hip, exit code 0 iff none differs"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from raytracingo_amd import _build
+    exe = str(tmp_path / "lean_ops_probe")
+    subprocess.check_call([_build.HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(root, "tools", "lean_ops_probe.hip")])
+    r = subprocess.run([exe, str(1 << 30)], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "division differs on 0, sqrt on 0" in r.stdout.splitlines()[0] and "division differs on 0, sqrt on 0" in r.stdout.splitlines()[1], r.stdout
+
+
+@pytest.mark.gpu
 def test_both_walks_agree_on_every_ray(tmp_path):
     """the -DRTGO_CMPWALK build of the library runs the fast walk next to the canonical one on EVERY ray of an instrumented launch
     and records the rays on which hit, t, primitive or normal differ (tools/cmp_walks.py): all 8 scenes x 3 modes, none"""
