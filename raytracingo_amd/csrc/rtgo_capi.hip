@@ -57,6 +57,7 @@ struct rtgo_ctx {
     int n_small = 0;
     int n_fnodes = 0;             // nodes of the fast walk's tree
     int cuboid_groups = 0;        // certified groups in the scene (leaves + the list's)
+    int tree_spheres = 0;         // every primitive of the fast walk's tree is a sphere
     int list_cub = 0;             // the up-front list starts with a certified box (1) / room (2): cuboid_range
     float cub_a = 0.0f, cub_b = 0.0f;   // its margin = kCuboidTol + K (cub_a R + cub_b), R = reach of the launch's rays
     int n_big_pairs = 0;
@@ -455,7 +456,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
                        (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight, std::getenv("RTGO_NO_CUBOID") ? 0 : 1);
     RTGO_HIP(c, hipGetLastError());
-    int meta[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int meta[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
     c->tight.assign((size_t)n * 6, 0.0f);
     RTGO_HIP(c, hipMemcpyAsync(c->tight.data(), c->d_tight, (size_t)n * 6 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -467,6 +468,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     c->n_big_pairs = meta[9] & 0xFF;
     c->list_cub = meta[9] >> 8;
     c->cuboid_groups = meta[13] + (c->list_cub ? 1 : 0);
+    c->tree_spheres = (c->n_small > 0 && meta[14] == (1 << 3) && !std::getenv("RTGO_NO_SPHERE_LEAVES")) ? 1 : 0;   // (type 3 = sphere)
     std::memcpy(&c->cub_a, &meta[11], sizeof(float));
     std::memcpy(&c->cub_b, &meta[12], sizeof(float));
     c->n_fnodes = meta[10];
@@ -623,6 +625,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         // build's A, B = max over (f, g) of L_fg |row_f|_1 + |row_g|_1 and of L_fg |w_f| + |w_g|.
         p.cub_mu = kCuboidTol + 64.0f * 5.9604645e-8f * (c->cub_a * 3.0f * reach + c->cub_b);
         p.list_cub = c->list_cub;
+        p.tree_spheres = c->tree_spheres;
         if (!(p.cub_mu < 0.02f)) {   // (tiny faces far from the origin: the margin would let two faces through too often to pay)
             p.list_cub = 0;
             p.cub_mu = -1.0f;        // tree leaves: cuboid_range is not taken either (see render_kernel)

@@ -51,6 +51,7 @@ struct LaunchParams {
     int n_big_pairs;                // ... of which the first 2*n_big_pairs records are pairs of opposite rectangles (pair_test)
     int list_cub;                   // 1 / 2: the up-front list starts with three pairs certified as one box / one room (cuboid_range), 0: it does not
     float cub_mu;                   // cuboid_range's margin for this launch (object-space units of a face's y axis)
+    int tree_spheres;               // 1: every primitive of the fast walk's tree is a sphere (balls): leaves go straight to the sphere test
     const LightRec* lights;
     float4* accum;
     uchar4* image;
@@ -684,9 +685,36 @@ __device__ __forceinline__ void fast_list(const float4* __restrict__ s_fprims, c
     }
 }
 
+// A leaf of a tree that holds nothing but spheres (a scene-wide fact the build reports): __intersection__sphere (kernel.cu:250-287)
+// without the per-lane dispatch on the primitive's type that leaf_test opens with -- three exec-masked regions per leaf phase that
+// a wave of sphere leaves walks through for nothing
+__device__ __forceinline__ void sphere_leaf(const float4* __restrict__ s_fprims, int first, int cnt, v3 wo, v3 wd, float tmin, FastHit& best)
+{
+    for (int k = 0; k < cnt; ++k) {
+        const int pos = first + k;
+        const float4 r0 = s_fprims[4 * pos + 0], r1 = s_fprims[4 * pos + 1], r2 = s_fprims[4 * pos + 2];
+        const int orig = __float_as_int(s_fprims[4 * pos + 3].y);
+        const v3 d = xf_dir(r0, r1, r2, wd);
+        const v3 o = xf_point(r0, r1, r2, wo);
+        const float a = vdot(d, d);
+        const float b = 2.0f * vdot(d, o);
+        const float c = vdot(o, o) - 1.0f;
+        const float discr = b * b - 4.0f * a * c;
+        if (discr > 0.0f) {
+            const float sdiscr = sqrt_cr(discr);
+            const float t = div_cr(-b - sdiscr, 2.0f * a);
+            if (t > 0.0001f && closer(t, orig, tmin, best)) {
+                best.t = t;
+                best.pos = pos;
+                best.orig = orig;
+            }
+        }
+    }
+}
+
 // fast_tree: the walk proper -- everything in the tree that can beat `best`
 __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims, unsigned int* __restrict__ s_stack, int bshift,
-                                          int n_small, float cub_mu, v3 o, v3 d, float tmin, FastHit& best, unsigned int& dbg_boxes, unsigned int& dbg_tests)
+                                          int n_small, float cub_mu, v3 o, v3 d, float tmin, FastHit& best, unsigned int& dbg_boxes, unsigned int& dbg_tests, bool tree_spheres)
 {
     // 1/d for the slab tests.  A direction component that is exactly zero is not rare: the hemisphere sample has sin(phi) = 0
     // whenever its random number is 0 (one ray in 2^24 per bounce, a few per 1080p frame), and cameras can be axis-aligned.
@@ -750,7 +778,8 @@ __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, c
 #ifdef RTGO_FAST_COUNTERS
             dbg_tests += (unsigned int)cnt;
 #endif
-            if (((-right) >> 20) != 0 && cub_mu > 0.0f) cuboid_range<false>(s_fprims, s_fprims, first, cub_mu, -INFINITY, o, d, tmin, best);
+            if (tree_spheres) sphere_leaf(s_fprims, first, cnt, o, d, tmin, best);
+            else if (((-right) >> 20) != 0 && cub_mu > 0.0f) cuboid_range<false>(s_fprims, s_fprims, first, cub_mu, -INFINITY, o, d, tmin, best);
             else leaf_range<false>(s_fprims, s_fprims, first, cnt, npairs, o, d, tmin, best);
             have = pop();
         }
@@ -786,7 +815,7 @@ __device__ __forceinline__ bool fast_winner(const float4* __restrict__ s_fprims,
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
                                                  const float4* __restrict__ g_fprims,
  unsigned int* __restrict__ s_stack, int bshift,
-                                                 int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, v3 o, v3 d, float tmin, float tmax, Hit& out,
+                                                 int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, bool tree_spheres, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests
 #ifdef RTGO_TIMELINE
                                                  , unsigned long long& tl_big, unsigned long long& tl_tree
@@ -808,7 +837,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     const unsigned long long tl_s1 = wall_clock64() + (best.pos == 12345 ? 1 : 0);
     tl_big += tl_s1 - tl_s0;
 #endif
-    fast_tree(s_fnodes, s_fprims, s_stack, bshift, n_small, cub_mu, o, d, tmin, best, dbg_boxes, dbg_tests);
+    fast_tree(s_fnodes, s_fprims, s_stack, bshift, n_small, cub_mu, o, d, tmin, best, dbg_boxes, dbg_tests, tree_spheres);
 #ifdef RTGO_TIMELINE
     tl_tree += wall_clock64() + (best.pos == 12345 ? 1 : 0) - tl_s1;
 #endif
@@ -1478,7 +1507,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     __shared__ unsigned char s_flag[kMaxPrims];         // fast walk: 1 = "big" primitive kept out of the tree
     __shared__ unsigned short s_order[kMaxPrims];       // fast walk: primitive at each record position (pairs side by side)
     __shared__ unsigned char s_used[kMaxPrims];
-    __shared__ int s_depth, s_count;
+    __shared__ int s_depth, s_count, s_tmask;   // s_tmask: primitive types present in the fast walk's tree (bit = type)
     // the bounds reductions run while s_nbox is not in use: borrow its storage (keeps static LDS under 64 KiB)
     float(*s_red)[kMaxPrims] = reinterpret_cast<float(*)[kMaxPrims]>(&s_nbox[0][0]);
 
@@ -1596,6 +1625,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
     if (i == 0) {
         s_depth = 0;
         s_count = 0;
+        s_tmask = 0;
     }
     // ---- per primitive: inverse, record, reference AABB
     PrimIn P;
@@ -1687,7 +1717,10 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
             if (s_box[i][3 + a] - s_box[i][a] >= big_frac * (s_red[3 + a][0] - s_red[a][0])) ++wide;
         big = wide >= 2;
         s_flag[i] = big ? 1 : 0;
-        if (!big) atomicAdd(&s_count, 1);
+        if (!big) {
+            atomicAdd(&s_count, 1);
+            atomicOr(&s_tmask, 1 << (int)(P.type & 3u));
+        }
     }
     __syncthreads();
     const int n_small = s_count;
@@ -2123,6 +2156,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         out_meta[1] = s_depth;
         out_meta[2] = n_small;
         out_meta[10] = s_count;   // nodes of the walk's tree (2 * units - 1)
+        out_meta[14] = s_tmask;
     }
 }
 
