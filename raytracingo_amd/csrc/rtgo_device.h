@@ -146,6 +146,36 @@ __device__ __forceinline__ float sqrt_cr(float x)
 #endif
 }
 
+// sincosf(x) for 0 <= x < 131072, finite: the device library's own small-argument path (three-constant Cody-Waite reduction by pi/2, its
+// two minimax polynomials, the quadrant logic) without what it wraps around it -- the test for the Payne-Hanek path, the sign of x, the
+// inf / NaN class test on both results.  GetRayOnHemisphere's angles are acos(..) in [0, pi/2] and 2 pi r in [0, 2 pi).
+// tools/lean_ops_probe.hip runs it against sincosf on EVERY float of [0, 8): identical bits.  -DRTGO_IEEE_OPS: the library call.
+__device__ __forceinline__ void sincos_cr(float x, float* s_out, float* c_out)
+{
+#ifdef RTGO_IEEE_OPS
+    sincosf(x, s_out, c_out);
+#else
+    const float n = rintf(x * __uint_as_float(0x3f22f983u));                  // x * 2/pi, to nearest even
+    const int ni = (int)n;
+    float r = fmaf(n, __uint_as_float(0xbfc90fdau), x);
+    r = fmaf(n, __uint_as_float(0xb3a22168u), r);
+    r = fmaf(n, __uint_as_float(0xa7c234c4u), r);
+    const float r2 = r * r;
+    float t = fmaf(__uint_as_float(0xb94c1982u), r2, __uint_as_float(0x3c0881c4u));
+    t = fmaf(r2, t, __uint_as_float(0xbe2aaa9du));
+    t = r2 * t;
+    const float sr = fmaf(r, t, r);
+    float u = fmaf(__uint_as_float(0x37d75334u), r2, __uint_as_float(0xbab64f3bu));
+    u = fmaf(r2, u, __uint_as_float(0x3d2aabf7u));
+    u = fmaf(r2, u, __uint_as_float(0xbf000004u));
+    const float cr = fmaf(r2, u, 1.0f);
+    const bool even = (ni & 1) == 0;
+    const unsigned int flip = ((unsigned int)ni << 30) & 0x80000000u;          // quadrants 2 and 3
+    *s_out = __uint_as_float(__float_as_uint(even ? sr : cr) ^ flip);
+    *c_out = __uint_as_float(__float_as_uint(even ? cr : -sr) ^ flip);
+#endif
+}
+
 __device__ __forceinline__ float vlength(v3 v) { return sqrt_cr(vdot(v, v)); }  // vec_math.h:535-538
 __device__ __forceinline__ v3 vnormalize(v3 v)                               // vec_math.h:541-545
 {
@@ -721,7 +751,7 @@ __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, c
     // rcp(0) = inf would turn fma(b, 1/d, -o/d) into inf - inf = NaN on one side of the origin and -inf on the other, and a
     // box straddling zero would be dropped; a huge FINITE reciprocal keeps both products finite and the slab's sign logic
     // intact (inside: (-huge, +huge); outside: both ends on one side).
-    auto safe_rcp = [](float x) { return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : __builtin_amdgcn_rcpf(x); };
+    auto safe_rcp = [](float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(x), -1e30f, 1e30f); };   // (rcp(+-0) = +-inf and anything beyond 1e30 end up at +-1e30)
     const v3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
     const v3 noid = mk(-(o.x * id.x), -(o.y * id.y), -(o.z * id.z));
     float tn;
@@ -882,9 +912,10 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
             theta = glossy_theta(base, expo);
         }
         float st, ct, sp, cp;
-        // sincosf shares the range reduction and returns bit for bit what sinf and cosf return (tools/sincos_probe.hip)
-        sincosf(theta, &st, &ct);
-        sincosf(phi, &sp, &cp);
+        // sincosf shares the range reduction and returns bit for bit what sinf and cosf return (tools/sincos_probe.hip); sincos_cr is its
+        // small-argument path alone
+        sincos_cr(theta, &st, &ct);
+        sincos_cr(phi, &sp, &cp);
         ray = vsub(vadd(vscale(X, st * cp), vscale(Y, ct)), vscale(Z, st * sp));
     } while (vdot(normal, ray) < 0.f);
     return ray;

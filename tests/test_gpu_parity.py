@@ -909,7 +909,7 @@ def test_cuboid_certificates_of_the_reference_scenes(capi, oracle):
 def test_lean_ops_are_ieee(tmp_path):
     """div_cr / sqrt_cr (rtgo_device.h: the compiler's own correctly rounded division and square root without the range plumbing around
     them) against the plain operators on the device, bit for bit, over 2^30 operand pairs per range drawn log-uniformly from the ranges
-    the kernels feed them: tools/lean_ops_probe.hip, exit code 0 iff none differs"""
+    the kernels feed them, and sincos_cr against the library's sincosf on every float of [0, 8]: tools/lean_ops_probe.hip, exit code 0 iff none differs"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -920,6 +920,7 @@ def test_lean_ops_are_ieee(tmp_path):
     r = subprocess.run([exe, str(1 << 30)], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "division differs on 0, sqrt on 0" in r.stdout.splitlines()[0] and "division differs on 0, sqrt on 0" in r.stdout.splitlines()[1], r.stdout
+    assert any(l.startswith("sincos_cr against sincosf on every float") and l.rstrip().endswith("differs on 0") for l in r.stdout.splitlines()), r.stdout
 
 
 @pytest.mark.gpu

@@ -36,6 +36,21 @@ __global__ void probe(unsigned long long n, int alo, int ahi, int blo, int bhi, 
     }
 }
 
+// sincos_cr against the library's sincosf on every float of [0, hi_bits]
+__global__ void probe_sincos(unsigned int hi_bits, unsigned long long* bad, float* first)
+{
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i <= hi_bits; i += stride) {
+        const float x = __uint_as_float((unsigned int)i);
+        float s0, c0, s1, c1;
+        sincosf(x, &s0, &c0);
+        rtgo::sincos_cr(x, &s1, &c1);
+        if (__float_as_uint(s0) != __float_as_uint(s1) || __float_as_uint(c0) != __float_as_uint(c1)) {
+            if (atomicAdd(bad, 1ull) == 0ull) { first[0] = x; first[1] = s0; first[2] = s1; first[3] = c0; first[4] = c1; }
+        }
+    }
+}
+
 __global__ void edges(const float* a, const float* b, int n, float* out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,6 +88,23 @@ int main(int argc, char** argv)
         if (bad[1]) printf("  (first: sqrt(%a) = %a, lean %a)", first[4], first[5], first[6]);
         printf("\n");
         if (r.must_match && (bad[0] || bad[1])) rc = 1;
+    }
+    {
+        unsigned long long bad = 0;
+        float first[8] = {0};
+        (void)hipMemset(d_bad, 0, sizeof bad);
+        (void)hipMemset(d_first, 0, sizeof first);
+        const float hi = 8.0f;
+        unsigned int hi_bits;
+        memcpy(&hi_bits, &hi, 4);
+        hipLaunchKernelGGL(probe_sincos, dim3(4096), dim3(256), 0, 0, hi_bits, d_bad, d_first);
+        if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "kernel failed\n"); return 2; }
+        (void)hipMemcpy(&bad, d_bad, sizeof bad, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(first, d_first, sizeof first, hipMemcpyDeviceToHost);
+        printf("sincos_cr against sincosf on every float of [0, 8] (%u values): differs on %llu", hi_bits + 1u, bad);
+        if (bad) printf("  (first: x = %a: sin %a / %a, cos %a / %a)", first[0], first[1], first[2], first[3], first[4]);
+        printf("\n");
+        if (bad) rc = 1;
     }
     // edge values: what the kernels can meet at the ends of the ranges (the lean forms need not equal IEEE on all of them; printed for the record,
     // the ones that matter are checked: 0 / b, a / b with an exactly representable quotient, sqrt(0))
