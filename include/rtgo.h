@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTGO_ABI_VERSION 3
+#define RTGO_ABI_VERSION 4
 #define RTGO_MAX_PRIMS 512  /* scene staged whole in LDS (largest reference scene: checkered, 390) */
 #define RTGO_MAX_LIGHTS 10  /* Params::MAX_LIGHTS, engine/params.h:115 */
 
@@ -103,9 +103,13 @@ typedef struct rtgo_stats {
     uint64_t rays_culled;     /* primary rays among rays_total that were answered (as misses) by the screen rectangle of the
                                  scene's bounds instead of a traversal; always 0 for collect_stats launches */
     uint32_t launches_canonical; /* launches since rtgo_reset_stats that walked the canonical LBVH: collect_stats launches, and
-                                    launches whose scene or eye reaches beyond 500 units (several times slower) */
+                                    launches beyond the far-field guard (guard_reach / guard_quadric below; several times slower;
+                                    DESIGN.md 3.2) */
     uint32_t cuboid_groups;   /* scene property: groups of three rectangle pairs the build certified as the faces of one box or room
                                  (tested by the fast walk's cuboid test); the up-front list's counts as one */
+    float guard_reach;        /* last launch: max(|scene bounds|, |eye|), world units -- the far-field guard's first quantity */
+    float guard_quadric;      /* last launch: max over spheres / cylinders of D^2 smax / smin^2 (D: farthest ray origin -- eye or scene
+                                 bounds -- to the primitive; s: its axis scales) -- the guard's second quantity; 0 without quadrics */
 } rtgo_stats;
 
 typedef struct rtgo_ctx rtgo_ctx;

@@ -58,7 +58,8 @@ class Stats(C.Structure):
                 ("prim_tests", C.c_uint64), ("hits", C.c_uint64), ("last_launch_ms", C.c_float),
                 ("total_launch_ms", C.c_float), ("launches", C.c_uint32), ("lbvh_depth", C.c_uint32),
                 ("dbg_fast_boxes", C.c_uint64), ("dbg_fast_tests", C.c_uint64), ("rays_culled", C.c_uint64),
-                ("launches_canonical", C.c_uint32), ("cuboid_groups", C.c_uint32)]
+                ("launches_canonical", C.c_uint32), ("cuboid_groups", C.c_uint32),
+                ("guard_reach", C.c_float), ("guard_quadric", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

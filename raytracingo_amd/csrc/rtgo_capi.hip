@@ -62,6 +62,13 @@ struct rtgo_ctx {
     float cub_a = 0.0f, cub_b = 0.0f;   // its margin = kCuboidTol + K (cub_a R + cub_b), R = reach of the launch's rays
     int n_big_pairs = 0;
     float bounds[6] = {0, 0, 0, 0, 0, 0};  // tight world bounds of the scene (min xyz, max xyz)
+    // far-field guard (rtgo_launch): per sphere / cylinder its centre and smax / smin^2 of its model matrix' axis scales -- the
+    // reported hit of a quadric seen from distance D lies up to ~2^-25 D^2 smax / smin^2 off its surface (b^2 - 4ac cancels)
+    struct Quadric {
+        float c[3], w;
+    };
+    std::vector<Quadric> quadrics;
+    float guard_reach = 0.0f, guard_quadric = 0.0f;   // of the last launch (rtgo_stats)
     float* d_tight = nullptr;              // the fast walk's box of every primitive (device), and its host copy
     std::vector<float> tight;
     // per-strip mask of the scene's screen rectangle (LaunchParams::hot_mask), kept until the launch geometry changes
@@ -131,21 +138,24 @@ using RenderKernel = void (*)(const LaunchParams, const float4*);
 struct RenderKernelEntry {
     bool path, canon, stream;
     int wpe;
+    bool count;
     RenderKernel fn;
 };
-#define RTGO_K(P, S, W, T) {P, S, T, W, render_kernel<P, S, W, T>}
+#define RTGO_K(P, S, W, T) {P, S, T, W, S, render_kernel<P, S, W, T>}
 static const RenderKernelEntry kRenderKernels[] = {
     RTGO_K(true, false, 4, false),  RTGO_K(true, false, 5, false),    // path mode, fast walk
     RTGO_K(false, false, 4, false), RTGO_K(false, false, 5, false),   // distributed mode, fast walk
     RTGO_K(true, false, 4, true),   RTGO_K(true, false, 5, true),     // ... more than 16 spp: lanes stream through their samples
     RTGO_K(false, false, 4, true),  RTGO_K(false, false, 5, true),
-    RTGO_K(true, true, 4, false),   RTGO_K(false, true, 4, false),    // canonical walk (+ counters)
+    RTGO_K(true, true, 4, false),   RTGO_K(false, true, 4, false),    // canonical walk + V/T/h counters (collect_stats launches)
+    {true, true, false, 4, false, render_kernel<true, true, 4, false, false>},     // canonical walk alone: launches beyond the far-field guard
+    {false, true, false, 4, false, render_kernel<false, true, 4, false, false>},
 };
 #undef RTGO_K
-static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream)
+static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream, bool count)
 {
     for (const RenderKernelEntry& e : kRenderKernels)
-        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe) && e.stream == (canon ? false : stream)) return e.fn;
+        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe) && e.stream == (canon ? false : stream) && e.count == (canon && count)) return e.fn;
     return nullptr;
 }
 
@@ -196,7 +206,25 @@ static uint32_t owned_rows_below(uint32_t y, uint32_t band_h, uint32_t n_ranks, 
 
 static inline uint32_t passes_of(uint32_t nn) { return (nn + (uint32_t)kSamplesPerPass - 1u) / (uint32_t)kSamplesPerPass; }
 
+// Far-field guard of rtgo_launch: the fast walk serves launches whose rays stay where every traversal returns the same closest hit;
+// beyond, the canonical walk ("far field").  Set from tools/fuzz_farfield.py (-DRTGO_CMPWALK build: both walks on
+// every ray; profiles/r03a/farfield_*.log: 3.6e9 rays over translated scenes and eye distances of 10 .. 3000 units):
+//   kGuardQuadric  max over spheres / cylinders of Q = D^2 smax / smin^2 (D: farthest ray origin -- eye or scene bounds -- to the
+//                  primitive; s: its axis scales).  A quadric's reported hit leaves its surface by ~2^-25 Q (b^2 - 4ac cancels), and
+//                  the reference's own box (AABB_EPSILON = 1e-3, primitive.cpp:16) no longer holds it from Q ~ 2^25 * 1e-3 = 33554 on.
+//                  Measured: no disagreement in 2.1e9 rays with Q < 32000, the first at Q = 33130; EVERY disagreement found, at any
+//                  distance, involves a sphere or a cylinder.  8000 = that onset with a safety factor of 4 on the error.
+//   kGuardReach    max(|scene bounds|, |eye|), world units, for what is linear in the coordinates (rectangles, disks, the cuboid
+//                  margin): 500.  Flat primitives never disagreed up to the largest reach fuzzed (5000): a factor of 10.
+static constexpr float kGuardReach = 500.0f;
+static constexpr float kGuardQuadric = 8000.0f;
+
 // tuning knobs for experiments (results never depend on them)
+static float env_float(const char* name, float dflt)
+{
+    const char* v = std::getenv(name);
+    return v ? (float)std::atof(v) : dflt;
+}
 static unsigned int env_uint(const char* name, unsigned int dflt)
 {
     const char* v = std::getenv(name);
@@ -482,6 +510,25 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: LBVH depth " + std::to_string(depth) + " exceeds the per-lane LDS stack (" +
                                                std::to_string(kStackDepth) + ")");
     c->n_prims = n;
+    c->quadrics.clear();
+    for (uint32_t i = 0; i < n; ++i) {
+        const rtgo_prim& q = prims[i];
+        if (q.type != RTGO_SPHERE && q.type != RTGO_CYLINDER) continue;
+        // axis scales = column norms of the model matrix' 3x3 (exact for translate * rotate * scale; a cylinder's quadratic lives in x, z)
+        double s[3];
+        for (int k = 0; k < 3; ++k) s[k] = std::sqrt((double)q.model[k] * q.model[k] + (double)q.model[4 + k] * q.model[4 + k] + (double)q.model[8 + k] * q.model[8 + k]);
+        double smin = s[0] < s[2] ? s[0] : s[2], smax = s[0] > s[2] ? s[0] : s[2];
+        if (q.type == RTGO_SPHERE) {
+            smin = s[1] < smin ? s[1] : smin;
+            smax = s[1] > smax ? s[1] : smax;
+        }
+        rtgo_ctx::Quadric e;
+        e.c[0] = q.model[3];
+        e.c[1] = q.model[7];
+        e.c[2] = q.model[11];
+        e.w = (float)(smax / (smin * smin));
+        c->quadrics.push_back(e);
+    }
     return RTGO_OK;
 }
 
@@ -617,7 +664,29 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         for (int k = 0; k < 6; ++k) reach = std::fabs(c->bounds[k]) > reach ? std::fabs(c->bounds[k]) : reach;
         const float e[3] = {p.eye.x, p.eye.y, p.eye.z};
         for (int k = 0; k < 3; ++k) reach = std::fabs(e[k]) > reach ? std::fabs(e[k]) : reach;
-        if (!(reach <= 500.0f)) canon = true;
+        // ... and a sphere's or cylinder's reported hit leaves its surface as the ray origin recedes: b^2 - 4ac cancels to the last
+        // bits of b^2 ~ D^2 / s^4, i.e. the hit lies up to ~2^-25 D^2 smax / smin^2 off the surface (D: origin to the primitive, s: its
+        // axis scales) -- outside the reference's own box when that exceeds AABB_EPSILON.  From there on no two traversals agree on
+        // grazing rays (the canonical LBVH culls such a hit by the primitive's box, a multi-primitive leaf's box lets it through, and
+        // OptiX promises neither), so what is bounded is Q = max over quadrics of D^2 smax / smin^2, D over the eye and the scene's
+        // tight bounds (where bounce rays start).  Thresholds: kGuardReach / kGuardQuadric, set from tools/fuzz_farfield.py's table
+        // (profiles/r03a) with the safety factors stated at their definition.
+        float quad = 0.0f;
+        for (const rtgo_ctx::Quadric& qd : c->quadrics) {
+            float d2 = 0.0f, e2 = 0.0f;
+            for (int k = 0; k < 3; ++k) {
+                const float lo = std::fabs(c->bounds[k] - qd.c[k]), hi = std::fabs(c->bounds[3 + k] - qd.c[k]);
+                const float far_k = lo > hi ? lo : hi;
+                d2 += far_k * far_k;
+                e2 += (e[k] - qd.c[k]) * (e[k] - qd.c[k]);
+            }
+            const float q2 = (d2 > e2 ? d2 : e2) * qd.w;
+            quad = q2 > quad ? q2 : quad;
+        }
+        c->guard_reach = reach;
+        c->guard_quadric = quad;
+        static const float guard_reach_max = env_float("RTGO_GUARD_REACH", kGuardReach), guard_quadric_max = env_float("RTGO_GUARD_QUADRIC", kGuardQuadric);
+        if (!(reach <= guard_reach_max) || !(quad <= guard_quadric_max)) canon = true;
         // cuboid_range's margin, in the object-space y units of a face g: the certificate's tolerance plus the rounding of what is
         // compared -- the reference's (u, v) on a face f, carried into y_g units by L_fg, and y_g(t_f) itself.  Each is a handful of
         // float operations on terms no larger than |row| (|o| + t |d|) + |w| <= |row|_1 * 3 reach + |w| (origins within `reach`, hit
@@ -850,8 +919,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     if (grid > need) grid = need;
 
     if (std::getenv("RTGO_DEBUG"))
-        std::fprintf(stderr, "rtgo_launch: %s walk%s, grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d, cuboid margin %g\n",
-                     canon ? "canonical" : "fast", (canon && !stats) ? " (scene or eye beyond 500 units)" : "", grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth, p.cub_mu);
+        std::fprintf(stderr, "rtgo_launch: %s walk%s, grid %u x %d threads, %zu B LDS, %d waves/SIMD variant, %d workgroups/CU, %u strips of %u px (%u x %u at %u,%u), %u cold segments in chunks of %u, stack %d, cuboid margin %g, guard reach %g quadric %g\n",
+                     canon ? "canonical" : "fast", (canon && !stats) ? " (beyond the far-field guard)" : "", grid, block, lds, wpe, blocks_per_cu, p.n_hot, strip_px, p.hot_w, p.hot_h, p.hot_x0, p.hot_y0, p.n_cold_segs, p.cold_cs, p.stack_depth, p.cub_mu, c->guard_reach, c->guard_quadric);
 #ifdef RTGO_TIMELINE
     c->timeline_waves = grid * (unsigned int)(block / 64);
     if (c->timeline_waves > 16384) return fail(c, RTGO_E_UNSUPPORTED, "timeline buffer too small");
@@ -865,7 +934,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     c->ev_tag[slot] = trial_tag;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const float4* fp = (const float4*)c->d_fprims;
-    const RenderKernel kernel = find_kernel(path, canon, wpe, stream);
+    const RenderKernel kernel = find_kernel(path, canon, wpe, stream, stats);
     if (!kernel) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: no kernel variant for this configuration");
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());
@@ -1164,6 +1233,8 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     out->rays_culled = c->rays_culled;
     out->launches_canonical = c->launches_canonical;
     out->cuboid_groups = (uint32_t)c->cuboid_groups;
+    out->guard_reach = c->guard_reach;
+    out->guard_quadric = c->guard_quadric;
     return RTGO_OK;
 }
 

@@ -1007,7 +1007,9 @@ __device__ __forceinline__ void cold_segment(const LaunchParams& p, unsigned int
 // budget costs (rtgo_capi.hip picks per launch; kRenderKernels there lists every instantiation).
 constexpr int kStreamWindow = 4;   // STREAM: passes a lane may run ahead of the oldest pass that is still open (192 floats of LDS per wave each)
 
-template <bool PATH, bool STATS, int WPE, bool STREAM>
+// COUNT: the canonical walk's V/T/h counters (collect_stats launches); the same walk without them serves launches beyond the
+// far-field guard, where it is the product path.
+template <bool PATH, bool STATS, int WPE, bool STREAM, bool COUNT = STATS>
 __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1390,7 +1392,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     // one atomic per wave per counter
     c_rays = wave_sum(c_rays);
     c_occl = wave_sum(c_occl);
-    if (STATS) {
+    if (COUNT) {
         c_nodes = wave_sum(c_nodes);
         c_tests = wave_sum(c_tests);
         c_hits = wave_sum(c_hits);
@@ -1418,7 +1420,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     if (lane == 0) {
         atomicAdd(&p.counters[0], (unsigned long long)c_rays);
         if (!PATH) atomicAdd(&p.counters[1], (unsigned long long)c_occl);
-        if (STATS && p.count_stats) {
+        if (COUNT && p.count_stats) {
             atomicAdd(&p.counters[2], (unsigned long long)c_nodes);
             atomicAdd(&p.counters[3], (unsigned long long)c_tests);
             atomicAdd(&p.counters[4], (unsigned long long)c_hits);

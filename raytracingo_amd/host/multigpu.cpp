@@ -341,6 +341,9 @@ rtgo_stats MultiGpuRenderer::Stats()
         tot.launches = s.launches;
         tot.launches_canonical += s.launches_canonical;
         tot.lbvh_depth = s.lbvh_depth;
+        tot.cuboid_groups = s.cuboid_groups;
+        tot.guard_reach = s.guard_reach;       // (the shares see one scene from one eye)
+        tot.guard_quadric = s.guard_quadric;
     }
     return tot;
 }

@@ -718,6 +718,59 @@ def test_far_camera_where_the_sphere_quadratic_loses_its_digits(capi, oracle):
     ctx.close()
 
 
+def _shifted_upload(capi, oracle, name, W, H, shift, eye_offset, fov=60.0):
+    """scene `name` moved by `shift`, seen from shift + eye_offset looking at its centre: (oracle scene, context)"""
+    sc = oracle.scene(name, W, H)
+    t = oracle.scene_tables(sc)
+    M = np.array(t["M"], dtype=np.float32).reshape(-1, 16).copy()
+    for k, col in enumerate((3, 7, 11)):
+        M[:, col] = (M[:, col] + np.float32(shift[k])).astype(np.float32)
+    L = np.array(t["lights"], dtype=np.float32).reshape(-1, 16).copy()
+    L[:, 0:3] = (L[:, 0:3] + oracle.f32(shift)).astype(np.float32)
+    eye, look, up = oracle.f32(np.asarray(shift) + np.asarray(eye_offset)), oracle.f32(shift), oracle.f32([0, 1, 0])
+    U, V, Wv = [np.zeros(3, dtype=np.float32) for _ in range(3)]
+    oracle.lib().oracle_camera_uvw(oracle.fptr(eye), oracle.fptr(look), oracle.fptr(up), fov, np.float32(np.float32(W) / np.float32(H)),
+                                   oracle.fptr(U), oracle.fptr(V), oracle.fptr(Wv))
+    cam = np.concatenate([eye, U, V, Wv]).astype(np.float32)
+    sc2 = oracle.scene_from_tables(t["type"], M, t["mat"], L, cam, t["bg"])     # (boxes by the CubeBox rule, like the device's)
+    ctx = capi.Context(0)
+    ctx.set_scene(t["type"], M, t["mat"], None)
+    ctx.set_camera(eye, U, V, Wv)
+    ctx.set_background(t["bg"])
+    ctx.set_lights(L)
+    return sc2, ctx
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("cornell", (290.0, 0.0, 0.0), (0.0, 0.0, 14.0), 60.0, False),      # reach ~ 304: flat primitives only
+                                  ("checkered", (-470.0, 10.0, 30.0), (0.0, 2.0, 14.0), 60.0, False),  # reach ~ 490, just inside
+                                  ("cornell", (0.0, 505.0, 0.0), (0.0, 0.0, 14.0), 60.0, True),        # reach ~ 509: beyond the reach guard
+                                  ("mirror_spheres", (0.0, 0.0, 0.0), (0.0, 0.0, 75.0), 12.0, False),  # quadric ~ 6.5e3: inside
+                                  ("mirror_spheres", (0.0, 0.0, 0.0), (0.0, 0.0, 95.0), 10.0, True),   # quadric ~ 1e4: beyond the quadric guard
+                                  ("plateau", (20.0, -15.0, 10.0), (30.0, 20.0, 40.0), 20.0, False),
+                                  ("balls", (0.0, 0.0, 0.0), (0.0, 0.0, 14.0), 60.0, False),           # the reference's own view: quadric ~ 2.1e3
+                                  ("slide", (0.0, 0.0, 0.0), (0.0, 0.0, 14.0), 60.0, True)])           # ... and the one reference view beyond: 4.3e4
+def test_far_field_guard(capi, oracle, case):
+    """The guard of rtgo_launch (rtgo_capi.hip: kGuardReach 500, kGuardQuadric 8000; evidence: profiles/r03a/farfield_*.log).  Inside it the
+    timed kernel walks the fast structure and its frame is the canonical walk's bit for bit; beyond it the product launch takes the
+    canonical walk (without counters) -- rtgo_stats says which ran and carries the two quantities."""
+    name, shift, eye_off, fov, beyond = case
+    W, H, n = 160, 90, 2
+    sc, ctx = _shifted_upload(capi, oracle, name, W, H, shift, eye_off, fov)
+    for path in (True, False):
+        ctx.reset_stats()
+        fast, fimg = gpu_render(capi, ctx, W, H, n, 0, path)
+        st = ctx.stats()
+        assert (st["guard_reach"] > 500.0 or st["guard_quadric"] > 8000.0) == beyond, st
+        assert st["launches_canonical"] == (1 if beyond else 0), st
+        canon, cimg = gpu_render(capi, ctx, W, H, n, 0, path, stats=True)
+        assert np.array_equal(fast.view(np.uint32), canon.view(np.uint32)) and np.array_equal(fimg, cimg), (case, path, st)
+        racc, rimg, _ = oracle.render(sc, oracle.frame(W, H, n, 0, path=path, mode=1))
+        assert_parity(canon, racc, cimg, rimg, what="far field %s path=%s" % (name, path))
+    print("far-field guard", name, "reach %.1f quadric %.0f" % (st["guard_reach"], st["guard_quadric"]), "canonical" if beyond else "fast")
+    ctx.close()
+
+
 @pytest.mark.gpu
 def test_smallest_and_largest_scenes(capi, oracle):
     """one primitive (no tree at all: the fast walk is its up-front list or a root leaf) and the maximum of 512 (every LDS array
