@@ -885,10 +885,22 @@ __device__ __attribute__((noinline)) float glossy_theta(float base, float expo)
 }
 
 // GetRayOnHemisphere, kernel.cu:101-122
+// UNIT_DIR: the caller's `direction` is a unit vector already (a normalised normal): kernel.cu:103 normalises it again, which moves it by
+// an ulp at most; the default build takes it as it is.
+// Diffuse lobe (coefficient 0: every path-mode bounce, kernel.cu:467): theta = acos(1 - r2) and then cos(theta), sin(theta) -- i.e.
+// cos = 1 - r2 (exact in float: r2 = k / 2^24) and sin = sqrt(r2 (2 - r2)), each within an ulp or two of what acosf / sinf / cosf
+// return, for a fifth of the instructions.  Both are inside the tolerance the contract states (1e-4 on >= 99 % of the pixels;
+// the reference's own build is --use_fast_math, CMakeLists.txt:165-170); the oracle keeps the libm calls.  Both walks share this code,
+// so fast == canonical stays bit for bit.  -DRTGO_LITERAL_SHADING: the literal forms (acosf, the second normalisation), as in round 2.
+template <bool UNIT_DIR>
 __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed)
 {
     v3 ray;
+#ifdef RTGO_LITERAL_SHADING
     const v3 Y = vnormalize(direction);
+#else
+    const v3 Y = UNIT_DIR ? direction : vnormalize(direction);
+#endif
     const v3 X = vnormalize(mk(Y.y - Y.z, -Y.x, Y.x));
     const v3 Z = vcross(Y, X);
     const float expo = div_cr(1.f, coefficient + 1.f);
@@ -897,24 +909,32 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
         const float r2 = rnd(seed);
         const float phi = 2.f * kPi * r1;
         const float base = 1.f - r2;
-        float theta;
-        if (expo == 1.0f) {
-            // diffuse lobe (every path-mode bounce): powf(x, 1) == x exactly in any sound libm
-            theta = acosf(base);
-        } else if (expo == 0.5f) {
-            // specularity 1 (every cornell surface in distributed mode): pow(x, 1/2) is sqrt(x), which IS correctly rounded on
-            // the device, and the lobe is as wide as the diffuse one, so float acosf is as benign here as it is there
-            theta = acosf(sqrt_cr(base));
-        } else {
-            // glossy lobe: acos(pow(x, 1/(coef+1))) sits at the ill-conditioned end of acos (argument within 1e-4 of 1),
-            // where one ulp of pow moves theta by ~1e-3 relative.  Evaluate both in f64 and round, which reproduces a
-            // correctly rounded float libm (tools/libm_probe: <0.02 % differing results vs 12 % / 28 % for the f32 forms).
-            theta = glossy_theta(base, expo);
-        }
         float st, ct, sp, cp;
-        // sincosf shares the range reduction and returns bit for bit what sinf and cosf return (tools/sincos_probe.hip); sincos_cr is its
-        // small-argument path alone
-        sincos_cr(theta, &st, &ct);
+#ifndef RTGO_LITERAL_SHADING
+        if (expo == 1.0f) {
+            ct = base;
+            st = sqrt_cr(r2 * (1.0f + base));
+        } else
+#endif
+        {
+            float theta;
+            if (expo == 1.0f) {
+                // diffuse lobe: powf(x, 1) == x exactly in any sound libm
+                theta = acosf(base);
+            } else if (expo == 0.5f) {
+                // specularity 1 (every cornell surface in distributed mode): pow(x, 1/2) is sqrt(x), which IS correctly rounded on
+                // the device, and the lobe is as wide as the diffuse one, so float acosf is as benign here as it is there
+                theta = acosf(sqrt_cr(base));
+            } else {
+                // glossy lobe: acos(pow(x, 1/(coef+1))) sits at the ill-conditioned end of acos (argument within 1e-4 of 1),
+                // where one ulp of pow moves theta by ~1e-3 relative.  Evaluate both in f64 and round, which reproduces a
+                // correctly rounded float libm (tools/libm_probe: <0.02 % differing results vs 12 % / 28 % for the f32 forms).
+                theta = glossy_theta(base, expo);
+            }
+            // sincosf shares the range reduction and returns bit for bit what sinf and cosf return (tools/sincos_probe.hip); sincos_cr is
+            // its small-argument path alone
+            sincos_cr(theta, &st, &ct);
+        }
         sincos_cr(phi, &sp, &cp);
         ray = vsub(vadd(vscale(X, st * cp), vscale(Y, ct)), vscale(Z, st * sp));
     } while (vdot(normal, ray) < 0.f);

@@ -18,7 +18,7 @@ What is compared, and what it can resolve (measured by tests/golden/ref_images/d
                          would leave everything but the light black).
 A screenshot of unknown frame count, JPEG coded, from a --use_fast_math build cannot be compared pixel by pixel; block means, region
 means and silhouettes can, and the thresholds below are the measured values with the stated margins.
-CPU tests render the oracle at 300 x 300 (seconds); the -m gpu tests render 600 x 600 at 1024 spp through the C ABI.
+CPU tests render the oracle at 300 x 300 (seconds); the -m gpu tests render 600 x 600 at 1024-4096 spp through the C ABI.
 """
 import numpy as np
 import pytest
@@ -154,10 +154,12 @@ def gpu():
 @pytest.mark.parametrize("white", [WHITE_OF_THE_PICTURE, None])
 def test_gpu_against_reference_jpg(gpu, oracle, white):
     capi, hscene = gpu
-    acc, st = refimg.gpu_render(capi, hscene, oracle, "reference", 600, 8, 16, white=white)      # 1024 spp
+    acc, st = refimg.gpu_render(capi, hscene, oracle, "reference", 600, 8, 64, white=white)      # 4096 spp
     assert st["launches_canonical"] == 0
-    # whole frame, 20 x 20 blocks: measured 0.46 with the oracle at 512 spp (floors: noise 0.36, JPEG 0.16); twice that is the bar
-    check_reference_jpg(acc, white if white is not None else 0.8, 1, block_mad_max=1.0)
+    # whole frame, 20 x 20 blocks: measured 0.46 with the oracle at 512 spp (floors: noise 0.36, JPEG 0.16); twice that is the bar.
+    # Regions: 0.05 -- the smallest one (the short box's top: 560 pixels under the light, a heavy-tailed estimator: 512-spp renders
+    # with 1, 4, 16, 64 samples per frame put it at 1.040, 1.024, 1.023, 1.041 of the picture) sets it; the others are within 0.03
+    check_reference_jpg(acc, white if white is not None else 0.8, 1, block_mad_max=1.0, tol=0.05)
     check_edges(refimg.display(refimg.to8(acc)), "reference")
     if white == WHITE_OF_THE_PICTURE:
         _, arr = refimg.fixtures()
