@@ -51,6 +51,7 @@ struct rtgo_ctx {
     float4* d_prims = nullptr;
     float4* d_fnodes = nullptr;   // collapsed LBVH of the fast walk
     float4* d_fprims = nullptr;   // Morton-ordered traversal records of the fast walk
+    float4* d_frames = nullptr;   // shading frames of the flat primitives (2 float4 per primitive, SBT order)
     int* d_meta = nullptr;
     int lbvh_depth = 0;
     int fast_depth = 0;
@@ -138,24 +139,29 @@ using RenderKernel = void (*)(const LaunchParams, const float4*);
 struct RenderKernelEntry {
     bool path, canon, stream;
     int wpe;
-    bool count;
+    bool count, frames;
     RenderKernel fn;
 };
-#define RTGO_K(P, S, W, T) {P, S, T, W, S, render_kernel<P, S, W, T>}
+#define RTGO_K(P, S, W, T) {P, S, T, W, S, false, render_kernel<P, S, W, T>}
+#define RTGO_KF(W, T) {true, false, T, W, false, true, render_kernel<true, false, W, T, false, true>}
 static const RenderKernelEntry kRenderKernels[] = {
     RTGO_K(true, false, 4, false),  RTGO_K(true, false, 5, false),    // path mode, fast walk
     RTGO_K(false, false, 4, false), RTGO_K(false, false, 5, false),   // distributed mode, fast walk
     RTGO_K(true, false, 4, true),   RTGO_K(true, false, 5, true),     // ... more than 16 spp: lanes stream through their samples
     RTGO_K(false, false, 4, true),  RTGO_K(false, false, 5, true),
     RTGO_K(true, true, 4, false),   RTGO_K(false, true, 4, false),    // canonical walk + V/T/h counters (collect_stats launches)
-    {true, true, false, 4, false, render_kernel<true, true, 4, false, false>},     // canonical walk alone: launches beyond the far-field guard
-    {false, true, false, 4, false, render_kernel<false, true, 4, false, false>},
+    {true, true, false, 4, false, false, render_kernel<true, true, 4, false, false>},     // canonical walk alone: launches beyond the far-field guard
+    {false, true, false, 4, false, false, render_kernel<false, true, 4, false, false>},
+    RTGO_KF(4, false), RTGO_KF(5, false), RTGO_KF(4, true), RTGO_KF(5, true),               // path mode, fast walk, scenes of flat primitives only: shading frames from LDS
 };
 #undef RTGO_K
-static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream, bool count)
+#undef RTGO_KF
+static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream, bool count, bool frames)
 {
     for (const RenderKernelEntry& e : kRenderKernels)
-        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe) && e.stream == (canon ? false : stream) && e.count == (canon && count)) return e.fn;
+        if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe) && e.stream == (canon ? false : stream) && e.count == (canon && count) &&
+            e.frames == (frames && path && !canon))
+            return e.fn;
     return nullptr;
 }
 
@@ -382,6 +388,7 @@ int rtgo_destroy(rtgo_ctx* c)
     (void)hipFree(c->d_prims);
     (void)hipFree(c->d_fnodes);
     (void)hipFree(c->d_fprims);
+    (void)hipFree(c->d_frames);
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_lights);
     if (c->own_output) {
@@ -456,7 +463,9 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     (void)hipFree(c->d_prims);
     (void)hipFree(c->d_fnodes);
     (void)hipFree(c->d_fprims);
+    (void)hipFree(c->d_frames);
     (void)hipFree(c->d_tight);
+    c->d_frames = nullptr;
     c->d_tight = nullptr;
     c->mask_key.clear();
     c->trial = rtgo_ctx::Trial();
@@ -473,6 +482,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     RTGO_HIP(c, hipMalloc(&c->d_prims, n * 6 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->d_fnodes, (2 * n - 1) * 2 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->d_fprims, n * 4 * sizeof(float4)));
+    RTGO_HIP(c, hipMalloc(&c->d_frames, n * 2 * sizeof(float4)));
     RTGO_HIP(c, hipMalloc(&c->d_tight, n * 6 * sizeof(float)));
     if (const char* k = std::getenv("RTGO_LEAF_BUDGET")) {  // tuning knob for experiments; results do not depend on it
         const int v = std::atoi(k);
@@ -482,7 +492,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     if (aabbs) RTGO_HIP(c, hipMemcpyAsync(c->d_aabb, aabbs, n * sizeof(rtgo_aabb), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), kBuildDynLds, c->stream, c->d_prims_in, c->d_aabb, aabbs ? 1 : 0, (int)n,
                        c->d_nodes, c->d_prims, c->d_fnodes, c->d_fprims, c->leaf_budget,
-                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight, std::getenv("RTGO_NO_CUBOID") ? 0 : 1);
+                       (float)env_uint("RTGO_BIG_PERCENT", 36) * 0.01f, c->d_meta, c->d_tight, std::getenv("RTGO_NO_CUBOID") ? 0 : 1, c->d_frames);
     RTGO_HIP(c, hipGetLastError());
     int meta[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(meta, c->d_meta, sizeof meta, hipMemcpyDeviceToHost, c->stream));
@@ -632,6 +642,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.Wv = c->W;
     p.bg = c->bg;
     const bool path = f->path_tracing != 0, stats = f->collect_stats != 0;
+    bool frames = false;   // (set once the walk is chosen)
     // scheduling: units of 64 paths = the N*N samples of `unit_px` neighbouring pixels of one row; the queue hands out STRIPS of
     // `grab` units side by side (<= 64 pixels) from the rectangle that can contain geometry.  Strips are long when there is
     // plenty of work (their pixel seeds are hashed once per strip) and short when units are scarce (small windows, one GPU's
@@ -813,6 +824,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     p.fnodes = c->d_fnodes;
     p.n_fnodes = c->n_fnodes;
     p.fprims = c->d_fprims;
+    p.frames = c->d_frames;
     p.n_small = c->n_small;
     p.n_big_pairs = c->n_big_pairs;
     p.stack_depth = canon ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1) + 1;   // (+1: fast_tree writes the slot past the top before it knows whether it pushes)
@@ -848,7 +860,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // The scene copy is per workgroup and the stack per lane, so bigger scenes want bigger workgroups: pick the size that
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
     const int fast_nodes = c->n_fnodes;
-    const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims) * sizeof(float4) +
+    frames = path && !canon && c->quadrics.empty() && !std::getenv("RTGO_NO_FRAMES");   // scenes of flat primitives only: N and the sampling tangent from LDS
+    const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims + (frames ? 2 * p.n_prims : 0) /* shading frames */) * sizeof(float4) +
                              (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float) +   // + the raygen constants
                              (size_t)(nn < (uint32_t)kSampleTab ? nn : (uint32_t)kSampleTab) * sizeof(uint4);   // + the per-sample start table
     int block = 0, blocks_per_cu = 0, best_waves = 0, wpe = 4;
@@ -934,7 +947,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     c->ev_tag[slot] = trial_tag;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const float4* fp = (const float4*)c->d_fprims;
-    const RenderKernel kernel = find_kernel(path, canon, wpe, stream, stats);
+    const RenderKernel kernel = find_kernel(path, canon, wpe, stream, stats, frames);
     if (!kernel) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: no kernel variant for this configuration");
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());

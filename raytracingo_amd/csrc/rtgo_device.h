@@ -46,6 +46,7 @@ struct LaunchParams {
     const float4* fnodes;           // the fast walk's tree: 2 float4 per node, root 0; leaf: left = first record, right = -(count | pairs << 12)
     int n_fnodes;
     const float4* fprims;           // 4 float4 per primitive in Morton order: rows 0..2 of M^-1, (bits(type), bits(SBT index), 0, 0)
+    const float4* frames;           // 2 float4 per primitive, SBT order: the shading frame of a flat primitive (see build_kernel), w of the first = 1 when it has one
     int stack_depth;                // per-lane LDS stack entries this launch needs
     int n_small;                    // fast walk: fprims [0, n_small) are in the tree, [n_small, n_prims) are tested up front
     int n_big_pairs;                // ... of which the first 2*n_big_pairs records are pairs of opposite rectangles (pair_test)
@@ -348,7 +349,7 @@ __device__ __forceinline__ bool box_test(const float4 q0, const float4 q1, v3 o,
 
 struct Hit {
     float t;
-    v3 n;
+    v3 n;      // world-space normal, not normalised (TransformNormal); not filled in for flat winners of the fast walk: their frame is in LDS
     int prim;
 };
 
@@ -692,8 +693,12 @@ __device__ __forceinline__ bool box_fast(const float4 q0, const float4 q1, v3 id
     tn = fmaxf(tn, tmin);
     tf = fminf(tf, tmax);
     tn_out = tn;
+#ifdef RTGO_NO_WIDEN
+    return tn <= tf;
+#else
     // widen by a few ulps so that the reciprocal's rounding can never drop a box the exact test keeps
     return tn <= tf * 1.000002f + 1e-7f;
+#endif
 }
 
 
@@ -837,7 +842,7 @@ __device__ __forceinline__ bool fast_winner(const float4* __restrict__ s_fprims,
         const v3 at = sphere ? vadd(oo, vscale(od, best.t)) : mk(oo.x + best.t * od.x, 0.0f, oo.z + best.t * od.z);
         nobj = sphere ? vnormalize(at) : at;
     }
-    out.n = xf_normal(r0, r1, r2, nobj);
+    out.n = xf_normal(r0, r1, r2, nobj);   // (flat winners: the closest-hit code takes the primitive's precomputed frame instead and this is dead code there)
     out.prim = best.orig;
     return true;
 }
@@ -892,16 +897,24 @@ __device__ __attribute__((noinline)) float glossy_theta(float base, float expo)
 // return, for a fifth of the instructions.  Both are inside the tolerance the contract states (1e-4 on >= 99 % of the pixels;
 // the reference's own build is --use_fast_math, CMakeLists.txt:165-170); the oracle keeps the libm calls.  Both walks share this code,
 // so fast == canonical stays bit for bit.  -DRTGO_LITERAL_SHADING: the literal forms (acosf, the second normalisation), as in round 2.
-template <bool UNIT_DIR>
-__device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed)
+// LEAN is set by path mode only: a diffuse bounce forgets the incoming direction, so an ulp in the hit point stays an ulp.  Distributed
+// mode keeps the literal forms: its mirror and glossy bounces off small spheres multiply a direction's last bit by ~2 d / r per bounce
+// (balls: 3.5 % of the pixels of a 96 x 64 frame left the tolerance when it ran lean, profiles/r03c).
+// have_x / Xpre: the tangent X of this direction is known already (a flat primitive's frame from build_kernel, bit for bit the value
+// computed here): lanes that have it skip the normalisation (a wave vote skips it altogether when every lane has).
+template <bool LEAN_IN>
+__device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed, bool have_x = false, v3 Xpre = v3{0.0f, 0.0f, 0.0f})
 {
     v3 ray;
 #ifdef RTGO_LITERAL_SHADING
-    const v3 Y = vnormalize(direction);
+    constexpr bool LEAN = false;
 #else
-    const v3 Y = UNIT_DIR ? direction : vnormalize(direction);
+    constexpr bool LEAN = LEAN_IN;
 #endif
-    const v3 X = vnormalize(mk(Y.y - Y.z, -Y.x, Y.x));
+    const v3 Y = LEAN ? direction : vnormalize(direction);   // (lean callers pass a unit vector: a normalised normal)
+    v3 X;
+    if (have_x) X = Xpre;   // (wave-uniform: LaunchParams::all_flat)
+    else X = vnormalize(mk(Y.y - Y.z, -Y.x, Y.x));
     const v3 Z = vcross(Y, X);
     const float expo = div_cr(1.f, coefficient + 1.f);
     do {
@@ -910,13 +923,10 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
         const float phi = 2.f * kPi * r1;
         const float base = 1.f - r2;
         float st, ct, sp, cp;
-#ifndef RTGO_LITERAL_SHADING
-        if (expo == 1.0f) {
+        if (LEAN && expo == 1.0f) {
             ct = base;
             st = sqrt_cr(r2 * (1.0f + base));
-        } else
-#endif
-        {
+        } else {
             float theta;
             if (expo == 1.0f) {
                 // diffuse lobe: powf(x, 1) == x exactly in any sound libm
@@ -1029,18 +1039,22 @@ constexpr int kStreamWindow = 4;   // STREAM: passes a lane may run ahead of the
 
 // COUNT: the canonical walk's V/T/h counters (collect_stats launches); the same walk without them serves launches beyond the
 // far-field guard, where it is the product path.
-template <bool PATH, bool STATS, int WPE, bool STREAM, bool COUNT = STATS>
+// FRAMES: the scene holds flat primitives only (cornell, checkered): closest-hit takes N and the sampling tangent from the frames
+// build_kernel computed (bit for bit the per-hit values); an instantiation of its own, so that the other scenes' code is untouched.
+template <bool PATH, bool STATS, int WPE, bool STREAM, bool COUNT = STATS, bool FRAMES = false>
 __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][stack][lights]
-    //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][stack, 4 B/entry][lights]
+    // LDS image.  STATS (canonical, instrumented walk): [nodes 2/node][prims 6/prim, SBT order][frames 2/prim][stack][lights]
+    //             fast walk (the timed kernel):          [fnodes 2/node][fprims 4/prim, Morton order][materials 3/prim][frames 2/prim][stack, 4 B/entry][lights]
     constexpr int MS = STATS ? 6 : 3;  // float4 stride between two primitives' material rows (kd|spec, kr|type, Le)
     const int n_nodes = STATS ? p.n_nodes : p.n_fnodes;
     float4* s_nodes = reinterpret_cast<float4*>(smem);
     float4* s_prims = s_nodes + 2 * n_nodes;
     float4* s_mat_w = STATS ? s_prims + 3 : s_prims + 4 * p.n_prims;
-    float4* s_end = STATS ? s_prims + 6 * p.n_prims : s_mat_w + 3 * p.n_prims;
+    float4* s_frame_w = STATS ? s_prims + 6 * p.n_prims : s_mat_w + 3 * p.n_prims;   // shading frames of the flat primitives, 2 float4 per primitive, SBT order
+    float4* s_end = s_frame_w + (FRAMES ? 2 * p.n_prims : 0);   // (only the instantiation that uses them pays for them)
+    const float4* s_frame = s_frame_w;
     float2* s_stack_base = reinterpret_cast<float2*>(s_end);
     const int stack_depth = STATS ? kStackDepth : p.stack_depth;
     const int kBlock = (int)blockDim.x;           // 256, 512 or 1024
@@ -1082,6 +1096,8 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
         for (int i = tid; i < 4 * p.n_prims; i += kBlock) s_prims[i] = p.fprims[i];
         for (int i = tid; i < 3 * p.n_prims; i += kBlock) s_mat_w[i] = p.prims[6 * (i / 3) + 3 + (i % 3)];
     }
+    if (FRAMES)
+        for (int i = tid; i < 2 * p.n_prims; i += kBlock) s_frame_w[i] = p.frames[i];
     for (unsigned int k = threadIdx.x; k < n_tab; k += blockDim.x) {
         const unsigned int si = k / (unsigned int)p.sqrt_spp;
         s_tab[k] = make_uint4(lcg_skip(1u, 2u * k) - lcg_skip(0u, 2u * k), lcg_skip(0u, 2u * k), si, k - si * (unsigned int)p.sqrt_spp);   // A = map(1) - map(0), C = map(0)
@@ -1547,7 +1563,7 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
                                                           int have_aabb, int n, float4* __restrict__ out_nodes,
                                                           float4* __restrict__ out_prims, float4* __restrict__ out_fnodes,
                                                           float4* __restrict__ out_fprims, int leaf_budget, float big_frac, int* __restrict__ out_meta,
-                                                          float* __restrict__ out_tight, int cuboids)
+                                                          float* __restrict__ out_tight, int cuboids, float4* __restrict__ out_frames)
 {
     __shared__ float s_box[kMaxPrims][6];               // per primitive: reference AABB, later the tight box
     __shared__ unsigned long long s_keys[kMaxPrims];
@@ -1692,6 +1708,21 @@ __global__ __launch_bounds__(kMaxPrims) void build_kernel(const PrimIn* __restri
         out_prims[6 * i + 3] = make_float4(P.kd[0], P.kd[1], P.kd[2], P.spec);
         out_prims[6 * i + 4] = make_float4(P.kr[0], P.kr[1], P.kr[2], __int_as_float((int)P.type));
         out_prims[6 * i + 5] = make_float4(P.Le[0], P.Le[1], P.Le[2], 0.0f);
+        // Shading frame of a FLAT primitive (rectangle, disk: object-space normal (0,1,0), kernel.cu:345,388): what the closest-hit
+        // program computes from it on every hit -- N = normalize(TransformNormal(0,1,0)) (kernel.cu:428) and the tangent of
+        // GetRayOnHemisphere for direction N, X = normalize(N.y - N.z, -N.x, N.x) (kernel.cu:105) -- depends on the primitive alone.
+        // Computed here ONCE with the same device functions on the same values, so the bits are those of the per-hit computation;
+        // a flipped normal flips both exactly (the expressions are odd in N, negation is exact), and Z = N x X is unchanged.
+        {
+            const bool flat = P.type == 1u || P.type == 2u;
+            v3 fn = mk(0.0f, 0.0f, 0.0f), fx = mk(0.0f, 0.0f, 0.0f);
+            if (flat) {
+                fn = vnormalize(xf_normal(make_float4(inv[0], inv[1], inv[2], inv[3]), make_float4(inv[4], inv[5], inv[6], inv[7]), make_float4(inv[8], inv[9], inv[10], inv[11]), mk(0.0f, 1.0f, 0.0f)));
+                fx = vnormalize(mk(fn.y - fn.z, -fn.x, fn.x));
+            }
+            out_frames[2 * i + 0] = make_float4(fn.x, fn.y, fn.z, flat ? 1.0f : 0.0f);
+            out_frames[2 * i + 1] = make_float4(fx.x, fx.y, fx.z, 0.0f);
+        }
         float bb[6];
         if (have_aabb) {
             for (int a = 0; a < 6; ++a) bb[a] = aabb_io[6 * i + a];

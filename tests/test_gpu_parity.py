@@ -718,6 +718,35 @@ def test_far_camera_where_the_sphere_quadratic_loses_its_digits(capi, oracle):
     ctx.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "checkered"])
+def test_precomputed_shading_frames_are_bitwise_the_per_hit_ones(capi, oracle, name, monkeypatch):
+    """scenes of flat primitives only: the path-mode kernel takes N = normalize(TransformNormal(0,1,0)) (kernel.cu:428) and
+    GetRayOnHemisphere's tangent (kernel.cu:105) from the frames build_kernel computed once per primitive (render_kernel<.., FRAMES>);
+    RTGO_NO_FRAMES launches the instantiation that computes them per hit: the same bits, at 16 and at 36 spp (lock-step and streaming)"""
+    W, H = 320, 180
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    for n in (4, 6):
+        prev = None
+        outs = []
+        for no_frames in (False, True):
+            if no_frames:
+                monkeypatch.setenv("RTGO_NO_FRAMES", "1")
+            else:
+                monkeypatch.delenv("RTGO_NO_FRAMES", raising=False)
+            acc = None
+            for f in range(2):
+                acc, img = gpu_render(capi, ctx, W, H, n, f, True, prev=acc)
+            outs.append((acc.copy(), img.copy()))
+        assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32)) and np.array_equal(outs[0][1], outs[1][1]), (name, n)
+        canon, cimg = None, None
+        for f in range(2):
+            canon, cimg = gpu_render(capi, ctx, W, H, n, f, True, stats=True, prev=canon)
+        assert np.array_equal(outs[0][0].view(np.uint32), canon.view(np.uint32)), (name, n)
+    monkeypatch.delenv("RTGO_NO_FRAMES", raising=False)
+    ctx.close()
+
+
 def _shifted_upload(capi, oracle, name, W, H, shift, eye_offset, fov=60.0):
     """scene `name` moved by `shift`, seen from shift + eye_offset looking at its centre: (oracle scene, context)"""
     sc = oracle.scene(name, W, H)
