@@ -3,7 +3,7 @@ import collections, csv, glob, json, os, sys
 
 d, tag = sys.argv[1], sys.argv[2]
 KERNEL = "render_kernel<true, false"   # any register-budget variant of the timed path-mode kernel
-out = {"tag": tag, "kernel": "rtgo::" + KERNEL}
+out = {"tag": tag, "kernel": "rtgo::" + KERNEL, "head": os.environ.get("RTGO_HEAD", "unknown")}   # RTGO_HEAD: the commit the profiled tree is (the GPU box has no .git)
 try:
     out["bench"] = json.loads([l for l in open(os.path.join(d, "bench.json")) if l.startswith("{")][-1])
 except Exception as e:
