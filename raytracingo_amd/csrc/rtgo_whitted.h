@@ -20,7 +20,7 @@ namespace whitted {
 
 constexpr int kMaxTriangles = 4096;   // one workgroup sorts the Morton keys in LDS (8 B per key)
 constexpr int kBuildThreads = 1024;
-constexpr int kStack = 32;            // bound on the depth of the Karras hierarchy the build accepts (fit passes, parent chains)
+constexpr int kStack = 32;            // the bottom-up fit runs 2 * kStack + 2 = 66 passes: enough for any Karras hierarchy over 30-bit codes of <= 4096 triangles (depth <= 42)
 constexpr int kRenderBlock = 1024;    // one workgroup per CU shares one LDS copy of the records
 #ifndef RTGO_LEAF_TRIS
 #define RTGO_LEAF_TRIS 4
@@ -31,7 +31,7 @@ constexpr int kMaxWalkDepth = 40;
 // triangle indices all in LDS
 constexpr int kAllInL2 = 0, kRecordsInLds = 1, kAllInLds = 2;
 constexpr int kTileHeads = 32;        // tile-queue heads (<= 64), kTileHeadStride words apart
-constexpr unsigned int kTileHeadStride = 16;     // per-lane stack entries (2 bytes each) the render kernel can be given
+constexpr unsigned int kTileHeadStride = 16;     // words between two heads: one 64-byte line each
 
 struct PointLight {   // Light::Point, cuda/Light.h:47-53
     float color[3];
@@ -908,7 +908,10 @@ __global__ __launch_bounds__(kBuildThreads) void sah_kernel(int n, const float4*
                     wl += u_w[u];
                     const float ex = a[3] - a[0], ey = a[4] - a[1], ez = a[5] - a[2];
                     const float cost = (ex * ey + ey * ez + ez * ex) * (float)wl + sfx[2 * j] * sfx[2 * j + 1];
-                    if (cost < best_cost) {
+                    // ties go to the split nearer the median: a range of leaves with one and the same box (coincident or duplicated
+                    // triangles) ties at every position, and "first wins" would peel one leaf per level -- a chain as deep as the range
+                    const int dj = j > m / 2 ? j - m / 2 : m / 2 - j, db = s_best_pos > m / 2 ? s_best_pos - m / 2 : m / 2 - s_best_pos;
+                    if (cost < best_cost || (cost == best_cost && dj < db)) {
                         best_cost = cost;
                         s_best_axis = pass;
                         s_best_pos = j;

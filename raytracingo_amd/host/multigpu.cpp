@@ -86,7 +86,9 @@ MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene, RenderMode rend
             gpu->commStream = gpu::StreamCreate(true);
             m_gpus.push_back(std::move(gpu));
             for (int i = 0; i < m_opt.launchesPerDevice; ++i) {
-                std::unique_ptr<Share> s(new Share());
+                // (in m_shares BEFORE anything that can throw: CleanUp then destroys whatever of it exists -- context, stream, buffers, events)
+                m_shares.push_back(std::unique_ptr<Share>(new Share()));
+                Share* s = m_shares.back().get();
                 s->gpu = g;
                 const int rc = rtgo_create(m_opt.devices[static_cast<size_t>(g)], &s->ctx);
                 if (rc != RTGO_OK) throw std::runtime_error(std::string("rtgo_create failed (") + std::to_string(rc) + "): " + rtgo_last_error(nullptr));
@@ -105,7 +107,6 @@ MultiGpuRenderer::MultiGpuRenderer(std::shared_ptr<Scene> scene, RenderMode rend
                     s->rendered[b] = gpu::EventCreate();
                     s->gathered[b] = gpu::EventCreate();
                 }
-                m_shares.push_back(std::move(s));
             }
         }
         gpu::SetDevice(m_gpus[0]->device);

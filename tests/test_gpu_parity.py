@@ -1242,3 +1242,27 @@ def test_whitted_edge_cases(capi, oracle):
     with pytest.raises(capi.RtgoError):
         ctx.whitted_set_mesh(one["positions"], None, one["indices"], np.array([1], np.uint32), one["materials"])  # material beyond the table
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_whitted_coincident_triangles(capi, oracle):
+    """200 copies of one triangle (every leaf box of the surface-area rebuild equal: its sweep ties at every split position) beside a
+    few distinct ones: the build must not turn the ties into a chain deeper than the walk's stack (ties go to the median; a tree that
+    still comes out too deep falls back to the Morton records), and the closest hit keeps the lowest triangle index"""
+    W, H = 64, 48
+    base = np.array([[-1.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.5, 0.0]], np.float32)
+    extra = np.array([[-2.0, 0.0, -1.0], [2.0, 0.0, -1.0], [0.0, 2.5, -1.0], [-0.5, 0.2, 0.5], [0.5, 0.2, 0.5], [0.0, 0.9, 0.5]], np.float32)
+    pos = np.concatenate([base, extra])
+    idx = np.array([[0, 1, 2]] * 200 + [[3, 4, 5], [6, 7, 8]], np.uint32)
+    mats = np.array([[0.7, 0.3, 0.2, 1, 0.0, 0.5], [0.2, 0.6, 0.8, 1, 0.3, 0.4]], np.float32)
+    mesh = {"positions": pos, "normals": None, "indices": idx, "tri_material": (np.arange(len(idx)) % 2).astype(np.uint32), "materials": mats,
+            "lights": np.array([[1, 1, 1, 4.0, 0.5, 2.0, 3.0, 0]], np.float32), "miss": np.array([0.02, 0.02, 0.05], np.float32)}
+    import whitted_scene
+    cam = whitted_scene.camera(oracle, W, H, eye=(0.3, 0.8, 4.0), lookat=(0, 0.7, 0))
+    ctx = _whitted_ctx(capi, mesh, cam, W, H)
+    ctx.whitted_launch(W, H, 0)
+    ctx.whitted_launch(W, H, 1)
+    ctx.sync()
+    racc, rimg, _ = oracle.whitted_render(mesh, cam, W, H, 2)
+    assert_parity(ctx.read_accum(H, W), racc, ctx.read_image(H, W), rimg, what="coincident triangles")
+    ctx.close()
