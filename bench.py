@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-frame band gather (diagnostic)")
     ap.add_argument("--launches-per-frame", type=int, default=0, choices=[0, 1, 2],
                     help="a rank renders its share as 1 launch, or as 2 half-share launches on two contexts / HIP streams so that "
-                         "the tail and launch latency of one overlap the body of the other (0 = 2 when N >= 4, else 1)")
+                         "the tail and launch latency of one overlap the body of the other (0 = 1: it stopped paying with round 3's kernel)")
     ap.add_argument("--single-rank-collectives", action="store_true",
                     help="developer check on a 1-GPU box: run the N>1 machinery (RCCL process group, comm stream, triple-buffered "
                          "bands, gather + de-interleave every frame) with a world of one rank. The JSON line is marked.")
@@ -162,8 +162,11 @@ def main():
     # S launches per frame and rank: the rank's share is cut into S sub-shares (virtual ranks v = rank*S + i of V = world*S in the
     # band interleave), each with its own context and HIP stream.  A short launch ends with a tail in which few waves are still
     # busy, and starts with ~13 us of launch latency; with two launches in flight one's tail and start overlap the other's body
-    # (a 1/8 share of the 1080p frame: 0.220 ms as one launch, 0.199 ms as two; a whole frame: 1.227 vs 1.243 -- hence N >= 4).
-    S = args.launches_per_frame if args.launches_per_frame else (2 if world >= 4 else 1)
+    # Round 1-2 kernels: a 1/8 share of the 1080p frame took 0.220 ms as one launch and 0.199 ms as two, hence S = 2 from N = 4 on.
+    # With round 3's kernel it no longer pays (profiles/r03f: 1/8 share 0.169 ms as one launch, 0.175 as two; 1/4: 0.275 / 0.295),
+    # and two launches, their events and stream waits cost this driver 0.19 ms of host time per step against 0.08 for one -- more
+    # than the share's kernel.  One launch per frame and rank, unless asked otherwise.
+    S = args.launches_per_frame if args.launches_per_frame else 1
     V = world * S
     ctxs = []
     for i in range(S):

@@ -26,7 +26,7 @@ static void printUsageAndExit(const char* argv0)
               << "         --out-accum=<file.pfm>      Write the float accumulation buffer (PFM)       [headless addition]\n"
               << "         --device=<i>                GPU index; default 0                          [headless addition]\n"
               << "         --gpus=<n>                  Tile the frame in 4-row bands over GPUs 0..n-1, RCCL gather to GPU 0 [multi-GPU addition]\n"
-              << "         --launches-per-gpu=<1|2>    Shares per GPU; default 2 when n >= 4           [multi-GPU addition]\n"
+              << "         --launches-per-gpu=<1|2>    Shares per GPU; default 1                       [multi-GPU addition]\n"
               << "         --present-every=<k>         Gather + assemble every k-th frame; default 1   [multi-GPU addition]\n";
     std::exit(1);
 }
@@ -90,7 +90,7 @@ int main(int argc, char* argv[])
         if (gpus >= 1) {
             engine::host::MultiGpuRenderer::Options opt;
             for (int g = 0; g < gpus; ++g) opt.devices.push_back(g);
-            opt.launchesPerDevice = launchesPerGpu > 0 ? launchesPerGpu : (gpus >= 4 ? 2 : 1);
+            opt.launchesPerDevice = launchesPerGpu > 0 ? launchesPerGpu : 1;   // (two half-share launches stopped paying with round 3's kernel: DESIGN.md section 6)
             opt.presentEvery = presentEvery;
             engine::host::MultiGpuRenderer renderer(sc, mode, sample, useAmbient, opt);
             renderer.SetFrames(frames);
