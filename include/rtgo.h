@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTGO_ABI_VERSION 4
+#define RTGO_ABI_VERSION 5
 #define RTGO_MAX_PRIMS 512  /* scene staged whole in LDS (largest reference scene: checkered, 390) */
 #define RTGO_MAX_LIGHTS 10  /* Params::MAX_LIGHTS, engine/params.h:115 */
 
@@ -182,12 +182,12 @@ int rtgo_read_bvh(rtgo_ctx* ctx, void* host_nodes, size_t node_bytes, void* host
 int rtgo_assemble_bands(rtgo_ctx* ctx, void* hip_stream, const void* d_gathered, void* d_full, uint32_t w, uint32_t h,
                         uint32_t band_h, uint32_t n_ranks, uint32_t rows_pad, uint32_t elem_bytes);
 
-/* ---- the "whitted" triangle path: cuda/whitted.cu + the mesh side of sutil/Scene.cpp, without textures or glTF loading ----------
+/* ---- the "whitted" triangle path: cuda/whitted.cu + the mesh side of sutil/Scene.cpp (no glTF loading: the caller parses its files) ----
    One launch = one subframe of whitted.cu's pipeline: __raygen__pinhole (tea<4> seed, sub-pixel jitter from subframe 1 on, running
    average, gamma-2.2 image), __closesthit__radiance (GGX / Smith / Schlick direct lighting of point lights, one occlusion ray per
    light), __closesthit__occlusion, __miss__constant_radiance.  Camera and output buffers are the context's (rtgo_set_camera,
    rtgo_resize / rtgo_bind_output, rtgo_read_image / rtgo_read_accum). */
-#define RTGO_MAX_TRIANGLES 4096
+#define RTGO_MAX_TRIANGLES 8192
 
 /* MaterialData::Pbr (cuda/MaterialData.h:43-52) without its three texture handles */
 typedef struct rtgo_pbr {
@@ -210,6 +210,25 @@ typedef struct rtgo_point_light {
    n_triangles <= RTGO_MAX_TRIANGLES.  Synchronous. */
 int rtgo_whitted_set_mesh(rtgo_ctx* ctx, const float* positions, const float* normals, uint32_t n_vertices, const uint32_t* indices,
                           const uint32_t* material_of_triangle, uint32_t n_triangles, const rtgo_pbr* materials, uint32_t n_materials);
+
+/* GeometryData::TriangleMesh::texcoords (cuda/GeometryData.h:46-52): one (u, v) per vertex of the mesh set by rtgo_whitted_set_mesh, or
+   NULL for none -- getLocalGeometry then takes the barycentrics as UV (cuda/LocalGeometry.h:88-102).  Call after rtgo_whitted_set_mesh. */
+int rtgo_whitted_set_texcoords(rtgo_ctx* ctx, const float* uv, uint32_t n_vertices);
+
+/* One image of sutil::Scene::addImage + addSampler (sutil/Scene.cpp:478-538): 8-bit RGBA texels in HOST memory, row 0 first (glTF's
+   v = 0 is the first row).  Sampled like the reference's cudaTextureObject_t: normalised coordinates, normalised float reads, no sRGB
+   decode, and -- addSampler compares its CUDA enum arguments with GL constants, so whatever the glTF sampler says -- wrap addressing and
+   bilinear filtering. */
+typedef struct rtgo_texture {
+    const void* rgba8;
+    uint32_t width, height;
+} rtgo_texture;
+
+/* MaterialData::Pbr::base_color_tex / metallic_roughness_tex / normal_tex (cuda/MaterialData.h:43-52) of material `material` of the table
+   given to rtgo_whitted_set_mesh; NULL = the material has no such texture (whitted.cu:264, 272, 288 test the handle).  The texels are
+   copied.  Call after rtgo_whitted_set_mesh (which clears every texture). */
+int rtgo_whitted_set_material_textures(rtgo_ctx* ctx, uint32_t material, const rtgo_texture* base_color,
+                                       const rtgo_texture* metallic_roughness, const rtgo_texture* normal);
 
 /* whitted::LaunchParams::lights (cuda/whitted.h:71); n <= RTGO_MAX_LIGHTS */
 int rtgo_whitted_set_lights(rtgo_ctx* ctx, const rtgo_point_light* lights, uint32_t n);

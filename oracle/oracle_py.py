@@ -61,7 +61,15 @@ class WhittedScene(C.Structure):
     _fields_ = [("positions", C.c_void_p), ("normals", C.c_void_p), ("indices", C.c_void_p), ("tri_material", C.c_void_p),
                 ("materials", C.c_void_p), ("lights", C.c_void_p), ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
                 ("n_materials", C.c_uint32), ("n_lights", C.c_uint32), ("eye", C.c_float * 3), ("U", C.c_float * 3),
-                ("V", C.c_float * 3), ("W", C.c_float * 3), ("miss", C.c_float * 3)]
+                ("V", C.c_float * 3), ("W", C.c_float * 3), ("miss", C.c_float * 3), ("texcoords", C.c_void_p), ("mat_tex", C.c_void_p)]
+
+
+class Tex(C.Structure):
+    _fields_ = [("px", C.c_void_p), ("w", C.c_uint32), ("h", C.c_uint32)]
+
+
+class MatTex(C.Structure):
+    _fields_ = [("base_color", Tex), ("metallic_roughness", Tex), ("normal", Tex)]
 
 
 def build(force=False):
@@ -115,6 +123,8 @@ def lib():
         L.oracle_whitted_render.restype = C.c_int
         L.oracle_whitted_render.argtypes = [C.POINTER(WhittedScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.POINTER(C.c_uint64), C.c_int]
+        L.oracle_tex2d.restype = None
+        L.oracle_tex2d.argtypes = [C.POINTER(Tex), C.c_float, C.c_float, fp]
         L.oracle_material.restype = C.c_int
         L.oracle_material.argtypes = [C.c_char_p, fp]
         L.oracle_lbvh_build.restype = C.c_int
@@ -244,6 +254,14 @@ def light_from_matrix(M, color=(1.0, 1.0, 1.0), falloff=0.0):
     return np.array(list(L.corner) + list(L.v1) + list(L.v2) + list(L.normal) + list(L.color) + [L.falloff], dtype=np.float32)
 
 
+def tex2d(texture, u, v):
+    """oracle_tex2d on a uint8 [h, w, 4] array"""
+    a = np.ascontiguousarray(texture, dtype=np.uint8)
+    out = np.zeros(4, dtype=np.float32)
+    lib().oracle_tex2d(C.byref(Tex(a.ctypes.data, a.shape[1], a.shape[0])), float(u), float(v), fptr(out))
+    return out
+
+
 def whitted_render(mesh, cam12, width, height, subframes=1, threads=0):
     """the oracle's whitted path (rtgo_oracle_whitted.c) over `subframes` accumulated subframes.
     mesh: dict(positions [nv,3] f32, normals [nv,3] f32 or None, indices [nt,3] u32, tri_material [nt] u32 or None,
@@ -263,6 +281,21 @@ def whitted_render(mesh, cam12, width, height, subframes=1, threads=0):
     cam = f32(cam12)
     s.eye[:], s.U[:], s.V[:], s.W[:] = cam[0:3].tolist(), cam[3:6].tolist(), cam[6:9].tolist(), cam[9:12].tolist()
     s.miss[:] = f32(mesh["miss"]).tolist()
+    # optional: texcoords [nv, 2] and textures = {material index: (base_color, metallic_roughness, normal)}, each uint8 [h, w, 4] or None
+    uv = None if mesh.get("texcoords") is None else np.ascontiguousarray(mesh["texcoords"], dtype=np.float32)
+    s.texcoords = uv.ctypes.data if uv is not None else None
+    keep = []
+    mt = None
+    if mesh.get("textures"):
+        mt = (MatTex * len(mats))()
+        for mi, triple in mesh["textures"].items():
+            for name, t in zip(("base_color", "metallic_roughness", "normal"), triple):
+                if t is None:
+                    continue
+                a = np.ascontiguousarray(t, dtype=np.uint8)
+                keep.append(a)
+                setattr(mt[mi], name, Tex(a.ctypes.data, a.shape[1], a.shape[0]))
+        s.mat_tex = C.addressof(mt)
     acc = np.zeros((height, width, 4), dtype=np.float32)
     img = np.zeros((height, width, 4), dtype=np.uint8)
     rays = (C.c_uint64 * 2)(0, 0)

@@ -137,7 +137,9 @@ int oracle_render(const oracle_scene* sc, const oracle_frame* fr, float* accum, 
 /* number of local rows a (window h, band_h, n_ranks, rank) owns */
 uint32_t oracle_local_rows(uint32_t h, uint32_t band_h, uint32_t n_ranks, uint32_t rank);
 
-/* ---- the "whitted" triangle path (rtgo_oracle_whitted.c): cuda/whitted.cu + cuda/LocalGeometry.h, no textures ---- */
+/* ---- the "whitted" triangle path (rtgo_oracle_whitted.c): cuda/whitted.cu + cuda/LocalGeometry.h ---- */
+typedef struct { const uint8_t* px; uint32_t w, h; } oracle_tex;                /* RGBA8, row 0 first; px NULL: none (sutil/Scene.cpp:505-538) */
+typedef struct { oracle_tex base_color, metallic_roughness, normal; } oracle_mat_tex;   /* MaterialData::Pbr's three handles */
 typedef struct { float base_color[4]; float metallic, roughness; } oracle_pbr;                               /* MaterialData::Pbr */
 typedef struct { float color[3]; float intensity; float position[3]; int32_t falloff; } oracle_point_light;   /* Light::Point */
 typedef struct {
@@ -149,7 +151,10 @@ typedef struct {
     const oracle_point_light* lights;
     uint32_t n_vertices, n_triangles, n_materials, n_lights;
     float eye[3], U[3], V[3], W[3], miss[3];
+    const float* texcoords;          /* 2 per vertex or NULL (UV = barycentrics, LocalGeometry.h:97-102) */
+    const oracle_mat_tex* mat_tex;   /* per material or NULL */
 } oracle_whitted_scene;
+void oracle_tex2d(const oracle_tex* t, float u, float v, float* rgba);                                        /* tex2D<float4>: wrap, bilinear, 1.8 fixed-point weights */
 uint32_t oracle_tea4(uint32_t v0, uint32_t v1);                                                               /* random.h:30-45, N = 4 */
 int oracle_tri_intersect(const float* p0, const float* p1, const float* p2, const float* o, const float* d, float tmin, float tmax,
                          float* t, float* u, float* v);

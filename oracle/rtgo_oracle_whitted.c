@@ -3,7 +3,8 @@
  *
  * Plain-C restatement of the reference's cuda/whitted.cu -- __raygen__pinhole (:183-240), __miss__constant_radiance
  * (:243-246), __closesthit__occlusion (:249-252), __closesthit__radiance (:255-337), the GGX helpers (:49-89), make_color
- * (:164-173) -- and of getLocalGeometry for triangle meshes (cuda/LocalGeometry.h:55-141), without textures.
+ * (:164-173) -- of getLocalGeometry for triangle meshes (cuda/LocalGeometry.h:55-141), and of tex2D<float4> on the texture objects
+ * sutil::Scene::addSampler makes (sutil/Scene.cpp:505-538; the filtering arithmetic is the CUDA programming guide's, "Texture Fetching").
  *
  * PINNING STATUS: tea<4> / rnd are held to the reference's own cuda/random.h through oracle/_ref (tests/golden/ref_blocks.json).
  * Everything else here is PARITY UNPINNED: whitted.cu includes <optix.h> (absent from this image), no program of the reference
@@ -65,6 +66,31 @@ int oracle_tri_intersect(const float* p0, const float* p1, const float* p2, cons
     *u_out = u;
     *v_out = v;
     return 1;
+}
+
+/* tex2D<float4>( tex, u, v ): cudaReadModeNormalizedFloat, normalizedCoords, and -- addSampler compares its CUDA enum arguments with GL
+   constants (Scene.cpp:517-524), so always -- cudaAddressModeWrap and cudaFilterModeLinear.  CUDA programming guide, linear filtering:
+   xB = u N - 0.5, i = floor(xB), alpha = frac(xB) in 1.8 fixed point (rounded to nearest here: the hardware's rounding is not published,
+   PARITY UNPINNED), tex = (1-a)(1-b) T[i,j] + a(1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1], indices wrapped.  Operation order
+   shared with the device code (rtgo_whitted.h, tex2d). */
+void oracle_tex2d(const oracle_tex* t, float u, float v, float* rgba)
+{
+    const float xb = u * (float)t->w - 0.5f, yb = v * (float)t->h - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = floorf((xb - fx) * 256.0f + 0.5f) * (1.0f / 256.0f), b = floorf((yb - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    const int w = (int)t->w, h = (int)t->h;
+    int i0 = (int)fx % w, j0 = (int)fy % h;
+    i0 += i0 < 0 ? w : 0;
+    j0 += j0 < 0 ? h : 0;
+    const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
+    const uint8_t* t00 = t->px + 4 * ((size_t)j0 * t->w + i0);
+    const uint8_t* t10 = t->px + 4 * ((size_t)j0 * t->w + i1);
+    const uint8_t* t01 = t->px + 4 * ((size_t)j1 * t->w + i0);
+    const uint8_t* t11 = t->px + 4 * ((size_t)j1 * t->w + i1);
+    const float k = 1.0f / 255.0f;
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    for (int c = 0; c < 4; ++c)
+        rgba[c] = w00 * ((float)t00[c] * k) + w10 * ((float)t10[c] * k) + w01 * ((float)t01[c] * k) + w11 * ((float)t11[c] * k);
 }
 
 static int trace(const oracle_whitted_scene* s, w3 o, w3 d, float tmin, float tmax, int any, int* tri, float* t, float* u, float* v)
@@ -150,9 +176,47 @@ int oracle_whitted_render(const oracle_whitted_scene* s, uint32_t width, uint32_
                     const w3 N0 = wld(s->normals, ix[0]), N1 = wld(s->normals, ix[1]), N2 = wld(s->normals, ix[2]);
                     N = wnormalize(wadd(wadd(wscale(N0, w0), wscale(N1, bu)), wscale(N2, bv)));
                 }
-                const oracle_pbr* m = s->materials + (s->tri_material ? s->tri_material[tri] : 0u);
-                const w3 base = W3(m->base_color[0], m->base_color[1], m->base_color[2]);
-                const float metallic = m->metallic * 1.0f, roughness = m->roughness * 1.0f; /* x the (1,1,1,1) of an absent texture */
+                const uint32_t mi = s->tri_material ? s->tri_material[tri] : 0u;
+                const oracle_pbr* m = s->materials + mi;
+                w3 base = W3(m->base_color[0], m->base_color[1], m->base_color[2]);
+                float mr_y = 1.0f, mr_z = 1.0f; /* the (1,1,1,1) of an absent metallic-roughness texture, whitted.cu:271 */
+                if (s->mat_tex) {
+                    const oracle_mat_tex* mt = s->mat_tex + mi;
+                    if (mt->base_color.px || mt->metallic_roughness.px || mt->normal.px) {
+                        /* getLocalGeometry's UV and dp/du, dp/dv (LocalGeometry.h:88-135) */
+                        float UV0[2] = { 0.0f, 0.0f }, UV1[2] = { 0.0f, 1.0f }, UV2[2] = { 1.0f, 0.0f }, UV[2] = { bu, bv };
+                        if (s->texcoords) {
+                            for (int k = 0; k < 2; ++k) {
+                                UV0[k] = s->texcoords[2 * ix[0] + k];
+                                UV1[k] = s->texcoords[2 * ix[1] + k];
+                                UV2[k] = s->texcoords[2 * ix[2] + k];
+                                UV[k] = w0 * UV0[k] + bu * UV1[k] + bv * UV2[k];
+                            }
+                        }
+                        float tc[4];
+                        if (mt->base_color.px) { /* base_color *= linearize( tex2D ), whitted.cu:78-85, 264-267 */
+                            oracle_tex2d(&mt->base_color, UV[0], UV[1], tc);
+                            base = wmul(base, W3(powf(tc[0], 2.2f), powf(tc[1], 2.2f), powf(tc[2], 2.2f)));
+                        }
+                        if (mt->metallic_roughness.px) { /* (occlusion, roughness, metallic), :272-276 */
+                            oracle_tex2d(&mt->metallic_roughness, UV[0], UV[1], tc);
+                            mr_y = tc[1];
+                            mr_z = tc[2];
+                        }
+                        if (mt->normal.px) { /* whitted.cu:288-292 over LocalGeometry.h:118-134 */
+                            const float du1 = UV0[0] - UV2[0], du2 = UV1[0] - UV2[0], dv1 = UV0[1] - UV2[1], dv2 = UV1[1] - UV2[1];
+                            const w3 dp1 = wsub(P0, P2), dp2 = wsub(P1, P2);
+                            const float det = du1 * dv2 - dv1 * du2;
+                            const float invdet = 1.0f / det;
+                            const w3 dpdu = wscale(wsub(wscale(dp1, dv2), wscale(dp2, dv1)), invdet);
+                            const w3 dpdv = wscale(wadd(wscale(dp1, -du2), wscale(dp2, du1)), invdet);
+                            oracle_tex2d(&mt->normal, UV[0], UV[1], tc);
+                            const float nx = 2.0f * tc[0] - 1.0f, ny = 2.0f * tc[1] - 1.0f, nz = 2.0f * tc[2] - 1.0f;
+                            N = wnormalize(wadd(wadd(wscale(wnormalize(dpdu), nx), wscale(wnormalize(dpdv), ny)), wscale(N, nz)));
+                        }
+                    }
+                }
+                const float metallic = m->metallic * mr_z, roughness = m->roughness * mr_y; /* :269-276 */
                 const float F0 = 0.04f;
                 const w3 diff_color = wscale(wscale(base, 1.0f - F0), 1.0f - metallic);
                 const w3 spec_color = wadd(W3(F0, F0, F0), wscale(wsub(base, W3(F0, F0, F0)), metallic)); /* lerp, vec_math.h:496-499 */

@@ -23,6 +23,7 @@ SYMBOLS = [
     "rtgo_read_image", "rtgo_read_accum", "rtgo_write_accum", "rtgo_get_stats", "rtgo_reset_stats", "rtgo_read_bvh",
     "rtgo_local_rows", "rtgo_abi_version", "rtgo_assemble_bands",
     "rtgo_whitted_set_mesh", "rtgo_whitted_set_lights", "rtgo_whitted_set_miss_color", "rtgo_whitted_launch",
+    "rtgo_whitted_set_texcoords", "rtgo_whitted_set_material_textures",
 ]
 
 
@@ -51,6 +52,10 @@ class Frame(C.Structure):
                 ("use_ambient", C.c_uint32), ("x0", C.c_uint32), ("y0", C.c_uint32), ("w", C.c_uint32),
                 ("h", C.c_uint32), ("band_h", C.c_uint32), ("n_ranks", C.c_uint32), ("rank", C.c_uint32),
                 ("collect_stats", C.c_uint32), ("reserve_cus", C.c_uint32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -106,6 +111,8 @@ def load():
     L.rtgo_whitted_set_lights.argtypes = [vp, vp, C.c_uint32]
     L.rtgo_whitted_set_miss_color.argtypes = [vp, fp]
     L.rtgo_whitted_launch.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.rtgo_whitted_set_texcoords.argtypes = [vp, vp, C.c_uint32]
+    L.rtgo_whitted_set_material_textures.argtypes = [vp, C.c_uint32, C.POINTER(Texture), C.POINTER(Texture), C.POINTER(Texture)]
     for name in SYMBOLS:
         fn = getattr(L, name)
         if fn.restype is C.c_int and name not in ("rtgo_last_error", "rtgo_local_rows", "rtgo_abi_version"):
@@ -235,6 +242,26 @@ class Context:
         self._check(self._lib.rtgo_whitted_set_mesh(self._h, pos.ctypes.data, nrm.ctypes.data if nrm is not None else None, len(pos),
                                                     idx.ctypes.data, tm.ctypes.data if tm is not None else None, len(idx),
                                                     mats.ctypes.data, len(mats)), "rtgo_whitted_set_mesh")
+
+    def whitted_set_texcoords(self, uv):
+        if uv is None:
+            self._check(self._lib.rtgo_whitted_set_texcoords(self._h, None, 0), "rtgo_whitted_set_texcoords")
+            return
+        a = np.ascontiguousarray(uv, dtype=np.float32).reshape(-1, 2)
+        self._check(self._lib.rtgo_whitted_set_texcoords(self._h, a.ctypes.data, len(a)), "rtgo_whitted_set_texcoords")
+
+    def whitted_set_material_textures(self, material, base_color=None, metallic_roughness=None, normal=None):
+        """each texture: uint8 array [h, w, 4] (row 0 first) or None"""
+        keep, ptrs = [], []
+        for t in (base_color, metallic_roughness, normal):
+            if t is None:
+                ptrs.append(None)
+                continue
+            a = np.ascontiguousarray(t, dtype=np.uint8)
+            assert a.ndim == 3 and a.shape[2] == 4
+            keep.append(a)
+            ptrs.append(C.pointer(Texture(a.ctypes.data, a.shape[1], a.shape[0])))
+        self._check(self._lib.rtgo_whitted_set_material_textures(self._h, int(material), ptrs[0], ptrs[1], ptrs[2]), "rtgo_whitted_set_material_textures")
 
     def whitted_set_lights(self, lights8):
         l = np.ascontiguousarray(lights8, dtype=np.float32).reshape(-1, 8)

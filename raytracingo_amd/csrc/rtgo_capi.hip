@@ -116,6 +116,10 @@ struct rtgo_ctx {
     unsigned int* w_tri_material = nullptr;
     whitted::Pbr* w_materials = nullptr;
     whitted::PointLight* w_lights = nullptr;
+    float* w_texcoords = nullptr;              // 2 floats per vertex, or null
+    whitted::MatTex* w_mat_tex = nullptr;      // device copy of w_mat_tex_host, or null while no material has a texture
+    std::vector<whitted::MatTex> w_mat_tex_host;
+    std::vector<void*> w_texels;               // device texel arrays the table points into (freed with the mesh)
     float4* w_nodes = nullptr;
     float4* w_recs = nullptr;              // the walk's records (4 float4 each) and the triangles in Morton order (3 float4 each)
     float4* w_tris = nullptr;
@@ -376,6 +380,7 @@ int rtgo_create(int device, rtgo_ctx** out)
     // (the build kernel holds ~58 KB of static LDS; its dynamic part is the fast walk's tree under construction)
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kBuildDynLds);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::sah_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+    if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::build_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(whitted::kMaxTriangles * sizeof(unsigned long long)));
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kAllInL2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kRecordsInLds>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (err == hipSuccess) err = hipFuncSetAttribute((const void*)whitted::render_kernel<whitted::kAllInLds>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -421,6 +426,9 @@ int rtgo_destroy(rtgo_ctx* c)
     (void)hipFree(c->w_indices);
     (void)hipFree(c->w_tri_material);
     (void)hipFree(c->w_materials);
+    (void)hipFree(c->w_texcoords);
+    (void)hipFree(c->w_mat_tex);
+    for (void* t : c->w_texels) (void)hipFree(t);
     (void)hipFree(c->w_lights);
     (void)hipFree(c->w_tile_counters);
     (void)hipFree(c->w_nodes);
@@ -1039,6 +1047,13 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     (void)hipFree(c->w_indices);
     (void)hipFree(c->w_tri_material);
     (void)hipFree(c->w_materials);
+    (void)hipFree(c->w_texcoords);
+    (void)hipFree(c->w_mat_tex);
+    for (void* t : c->w_texels) (void)hipFree(t);
+    c->w_texels.clear();
+    c->w_mat_tex_host.clear();
+    c->w_texcoords = nullptr;
+    c->w_mat_tex = nullptr;
     (void)hipFree(c->w_nodes);
     (void)hipFree(c->w_recs);
     (void)hipFree(c->w_tris);
@@ -1081,12 +1096,15 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     int* count_of = first_of + n_triangles;
     int* rec_of = count_of + n_triangles;
     int* meta = rec_of + n_triangles;
-    hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), 0, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
+    const size_t keys_lds = (size_t)whitted::kMaxTriangles * sizeof(unsigned long long);
+    hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), keys_lds, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
                        parent, visit, first_of, count_of, rec_of, c->w_recs, c->w_tris, c->w_qrecs, c->w_tidx, meta);
     RTGO_HIP(c, hipGetLastError());
-    if (!std::getenv("RTGO_WHITTED_NO_SAH")) {
-        // the records over the same leaves, rebuilt top-down with the surface-area heuristic (leaf boxes, links, order arrays in LDS)
-        const size_t sah_lds = (size_t)n_triangles * (6 * sizeof(float) + sizeof(int) + 2 * sizeof(short) + 1) + 16;
+    // the records over the same leaves, rebuilt top-down with the surface-area heuristic (leaf boxes, links, order arrays in LDS: 33 B per
+    // triangle, so meshes beyond ~4650 triangles keep the Morton records)
+    const size_t sah_lds = (size_t)n_triangles * (6 * sizeof(float) + sizeof(int) + 2 * sizeof(short) + 1) + 16;
+    const bool sah = !std::getenv("RTGO_WHITTED_NO_SAH") && sah_lds <= 150 * 1024;
+    if (sah) {
         hipLaunchKernelGGL(whitted::sah_kernel, dim3(1), dim3(whitted::kBuildThreads), sah_lds, c->stream, (int)n_triangles, (const float4*)c->w_nodes, (const int*)parent,
                            (const int*)first_of, (const int*)count_of, meta + 16, c->w_recs, c->w_qrecs, meta);
         RTGO_HIP(c, hipGetLastError());
@@ -1094,10 +1112,10 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     int m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     RTGO_HIP(c, hipMemcpyAsync(m, meta, sizeof m, hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
-    if (m[2] > whitted::kMaxWalkDepth && !std::getenv("RTGO_WHITTED_NO_SAH")) {
+    if (m[2] > whitted::kMaxWalkDepth && sah) {
         // the surface-area tree came out deeper than the walk's stack (it has no depth bound of its own): back to the Morton records,
         // whose depth is bounded by the code length
-        hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), 0, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
+        hipLaunchKernelGGL(whitted::build_kernel, dim3(1), dim3(whitted::kBuildThreads), keys_lds, c->stream, c->w_positions, c->w_indices, (int)n_triangles, c->w_nodes,
                            parent, visit, first_of, count_of, rec_of, c->w_recs, c->w_tris, c->w_qrecs, c->w_tidx, meta);
         RTGO_HIP(c, hipGetLastError());
         RTGO_HIP(c, hipMemcpyAsync(m, meta, sizeof m, hipMemcpyDeviceToHost, c->stream));
@@ -1122,6 +1140,56 @@ int rtgo_whitted_set_mesh(rtgo_ctx* c, const float* positions, const float* norm
     }
     c->w_triangles = (int)n_triangles;
     c->w_n_materials = (int)n_materials;
+    return RTGO_OK;
+}
+
+int rtgo_whitted_set_texcoords(rtgo_ctx* c, const float* uv, uint32_t n_vertices)
+{
+    if (!c) return RTGO_E_INVALID;
+    if (c->w_triangles == 0) return fail(c, RTGO_E_STATE, "rtgo_whitted_set_texcoords: no mesh (call rtgo_whitted_set_mesh first)");
+    if (uv && n_vertices != (uint32_t)c->w_n_vertices) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_texcoords: one (u, v) per vertex of the mesh");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(c->w_texcoords);
+    c->w_texcoords = nullptr;
+    if (uv) {
+        for (size_t k = 0; k < (size_t)n_vertices * 2; ++k)
+            if (!std::isfinite(uv[k])) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_texcoords: non-finite coordinate");
+        RTGO_HIP(c, hipMalloc(&c->w_texcoords, (size_t)n_vertices * 2 * sizeof(float)));
+        RTGO_HIP(c, hipMemcpyAsync(c->w_texcoords, uv, (size_t)n_vertices * 2 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return RTGO_OK;
+}
+
+int rtgo_whitted_set_material_textures(rtgo_ctx* c, uint32_t material, const rtgo_texture* base_color, const rtgo_texture* metallic_roughness,
+                                       const rtgo_texture* normal)
+{
+    if (!c) return RTGO_E_INVALID;
+    if (c->w_triangles == 0) return fail(c, RTGO_E_STATE, "rtgo_whitted_set_material_textures: no mesh (call rtgo_whitted_set_mesh first)");
+    if (material >= (uint32_t)c->w_n_materials) return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_material_textures: material index beyond the table");
+    const rtgo_texture* in[3] = {base_color, metallic_roughness, normal};
+    for (const rtgo_texture* t : in)
+        if (t && (!t->rgba8 || t->width == 0 || t->height == 0 || t->width > 16384 || t->height > 16384))
+            return fail(c, RTGO_E_INVALID, "rtgo_whitted_set_material_textures: a texture needs texels and a size in [1, 16384]^2");
+    RTGO_HIP(c, hipSetDevice(c->device));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->w_mat_tex_host.empty()) c->w_mat_tex_host.assign((size_t)c->w_n_materials, whitted::MatTex{{nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}});
+    whitted::Tex out[3];
+    for (int k = 0; k < 3; ++k) {
+        out[k] = whitted::Tex{nullptr, 0, 0};
+        if (!in[k]) continue;
+        const size_t bytes = (size_t)in[k]->width * in[k]->height * 4;
+        void* d = nullptr;
+        RTGO_HIP(c, hipMalloc(&d, bytes));
+        c->w_texels.push_back(d);
+        RTGO_HIP(c, hipMemcpyAsync(d, in[k]->rgba8, bytes, hipMemcpyHostToDevice, c->stream));
+        out[k] = whitted::Tex{(const uchar4*)d, in[k]->width, in[k]->height};
+    }
+    c->w_mat_tex_host[material] = whitted::MatTex{out[0], out[1], out[2]};   // (texels of a replaced entry stay allocated until the next set_mesh)
+    if (!c->w_mat_tex) RTGO_HIP(c, hipMalloc(&c->w_mat_tex, (size_t)c->w_n_materials * sizeof(whitted::MatTex)));
+    RTGO_HIP(c, hipMemcpyAsync(c->w_mat_tex, c->w_mat_tex_host.data(), (size_t)c->w_n_materials * sizeof(whitted::MatTex), hipMemcpyHostToDevice, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
     return RTGO_OK;
 }
 
@@ -1182,6 +1250,8 @@ int rtgo_whitted_launch(rtgo_ctx* c, uint32_t width, uint32_t height, uint32_t s
     p.normals = c->w_normals;
     p.indices = c->w_indices;
     p.tri_material = c->w_tri_material;
+    p.texcoords = c->w_texcoords;
+    p.mat_tex = c->w_mat_tex;
     p.materials = c->w_materials;
     p.lights = c->w_lights;
     p.n_triangles = c->w_triangles;

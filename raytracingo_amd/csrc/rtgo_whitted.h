@@ -18,9 +18,10 @@
 namespace rtgo {
 namespace whitted {
 
-constexpr int kMaxTriangles = 4096;   // one workgroup sorts the Morton keys in LDS (8 B per key)
+constexpr int kMaxTriangles = 8192;   // one workgroup sorts the Morton keys in (dynamic) LDS, 8 B per key; leaf codes and 2-byte stack entries hold 13 bits of triangle position
+constexpr int kLeafShift = 13;        // leaf code = first sorted triangle | (count - 1) << kLeafShift   (count <= 4: 15 bits, what a stack entry holds beside its flag)
 constexpr int kBuildThreads = 1024;
-constexpr int kStack = 32;            // the bottom-up fit runs 2 * kStack + 2 = 66 passes: enough for any Karras hierarchy over 30-bit codes of <= 4096 triangles (depth <= 42)
+constexpr int kStack = 32;            // the bottom-up fit runs 2 * kStack + 2 = 66 passes: enough for any Karras hierarchy over 30-bit codes of <= 8192 triangles (depth <= 43)
 constexpr int kRenderBlock = 1024;    // one workgroup per CU shares one LDS copy of the records
 #ifndef RTGO_LEAF_TRIS
 #define RTGO_LEAF_TRIS 4
@@ -45,9 +46,19 @@ struct Pbr {          // MaterialData::Pbr without its texture handles, cuda/Mat
     float metallic, roughness;
 };
 
+// one texture of a material (cudaTextureObject_t of sutil::Scene::addSampler, sutil/Scene.cpp:505-538: RGBA8 read as normalised floats,
+// normalised coordinates, and -- because addSampler compares its CUDA enums with GL constants -- always wrap addressing and linear filtering)
+struct Tex {
+    const uchar4* px;           // row 0 first; null: the material has no such texture
+    unsigned int w, h;
+};
+struct MatTex {                 // MaterialData::Pbr's three handles, cuda/MaterialData.h:43-52
+    Tex base_color, metallic_roughness, normal;
+};
+
 struct Params {       // whitted::LaunchParams, cuda/whitted.h:59-74
     const float4* recs;         // the walk's records, 4 float4 each: (left min, left link) (left max, -) (right min, right link) (right max, -);
-                                //   link >= 0: a record; link < 0: a leaf, -1 - (first sorted triangle | (count - 1) << 12)
+                                //   link >= 0: a record; link < 0: a leaf, -1 - (first sorted triangle | (count - 1) << kLeafShift)
     const float4* tris;         // 3 float4 per triangle in Morton order: (P0, original index) (P1, -) (P2, -)
     // the compact form of the same structure, for meshes that fit a CU's LDS whole (kAllInLds):
     const uint4* qrecs;         // 2 uint4 per record: (x, y, z planes of the left box as lo | hi << 16 on a 16-bit grid, left link), same for the right box
@@ -64,6 +75,8 @@ struct Params {       // whitted::LaunchParams, cuda/whitted.h:59-74
     const float* normals;       // 3 floats per vertex, or null (then N = Ng, LocalGeometry.h:113-116)
     const unsigned int* indices;    // 3 per triangle
     const unsigned int* tri_material;
+    const float* texcoords;     // 2 floats per vertex, or null (then UV = the barycentrics, LocalGeometry.h:97-102)
+    const MatTex* mat_tex;      // per material, or null when no material has a texture
     const Pbr* materials;
     const PointLight* lights;
     int n_triangles, n_lights;
@@ -203,7 +216,7 @@ __device__ __forceinline__ bool trace(const Params& p, Recs recs, unsigned short
                 }
             } else {
                 const int code = -1 - cur;
-                if (leaf_tris<ANY>(p.tris, code & 0xFFF, (code >> 12) + 1, o, d, tmin, tmax, best, best_pos, bt, bu, bv)) break;   // (true only when ANY)
+                if (leaf_tris<ANY>(p.tris, code & ((1 << kLeafShift) - 1), (code >> kLeafShift) + 1, o, d, tmin, tmax, best, best_pos, bt, bu, bv)) break;   // (true only when ANY)
             }
             if (pop) {
                 if (sp == 0) break;
@@ -240,6 +253,31 @@ __device__ __forceinline__ float ggx_normal(float NdotH, float alpha)
     const float n2 = NdotH * NdotH;
     const float x = n2 * (a2 - 1.0f) + 1.0f;
     return a2 / (kPi * x * x);
+}
+
+// tex2D<float4>( tex, u, v ) of a cudaReadModeNormalizedFloat / normalizedCoords / cudaAddressModeWrap / cudaFilterModeLinear texture, as
+// the CUDA programming guide states it (appendix "Texture Fetching", linear filtering): x = u N, xB = x - 0.5, i = floor(xB),
+// alpha = frac(xB) kept in 1.8 fixed point (8 fractional bits; rounded to nearest here -- the hardware's rounding is not published:
+// parity unpinned), tex = (1-a)(1-b) T[i,j] + a (1-b) T[i+1,j] + (1-a) b T[i,j+1] + a b T[i+1,j+1] with indices wrapped.
+// The operation order is the contract between this kernel and the oracle (oracle_tex2d).
+__device__ __forceinline__ float4 tex2d(const Tex t, float u, float v)
+{
+    const float xb = u * (float)t.w - 0.5f, yb = v * (float)t.h - 0.5f;
+    const float fx = floorf(xb), fy = floorf(yb);
+    const float a = floorf((xb - fx) * 256.0f + 0.5f) * (1.0f / 256.0f), b = floorf((yb - fy) * 256.0f + 0.5f) * (1.0f / 256.0f);
+    // wrap: floored modulo of the integer texel index (|u|, |v| stay far below 2^24 / N)
+    const int w = (int)t.w, h = (int)t.h;
+    int i0 = (int)fx % w, j0 = (int)fy % h;
+    i0 += i0 < 0 ? w : 0;
+    j0 += j0 < 0 ? h : 0;
+    const int i1 = i0 + 1 == w ? 0 : i0 + 1, j1 = j0 + 1 == h ? 0 : j0 + 1;
+    const uchar4 t00 = t.px[(size_t)j0 * t.w + i0], t10 = t.px[(size_t)j0 * t.w + i1], t01 = t.px[(size_t)j1 * t.w + i0], t11 = t.px[(size_t)j1 * t.w + i1];
+    const float k = 1.0f / 255.0f;
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    auto mix = [&](unsigned char c00, unsigned char c10, unsigned char c01, unsigned char c11) {
+        return w00 * ((float)c00 * k) + w10 * ((float)c10 * k) + w01 * ((float)c01 * k) + w11 * ((float)c11 * k);
+    };
+    return make_float4(mix(t00.x, t10.x, t01.x, t11.x), mix(t00.y, t10.y, t01.y, t11.y), mix(t00.z, t10.z, t01.z, t11.z), mix(t00.w, t10.w, t01.w, t11.w));
 }
 
 // ---- the walk over the LDS-resident compact form (kAllInLds) -------------------------------------------------------------
@@ -341,7 +379,7 @@ __device__ __forceinline__ bool trace_lds(const Params& p, const uint4* __restri
             }
             if (have) {
                 const int code = -1 - cur;
-                if (leaf_tris_lds<ANY>(s_verts, s_tidx, code & 0xFFF, (code >> 12) + 1, o, d, tmin, tmax, best, best_pos, bt, bu, bv)) break;   // (true only when ANY)
+                if (leaf_tris_lds<ANY>(s_verts, s_tidx, code & ((1 << kLeafShift) - 1), (code >> kLeafShift) + 1, o, d, tmin, tmax, best, best_pos, bt, bu, bv)) break;   // (true only when ANY)
                 pop();
             }
         }
@@ -471,7 +509,7 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
                     c0 = p.tris[3 * tpos + 0];
                     c1 = p.tris[3 * tpos + 1];
                     c2 = p.tris[3 * tpos + 2];
-                    if (p.normals) {
+                    if (p.normals || p.texcoords) {
                         i0 = p.indices[3 * tri + 0];
                         i1 = p.indices[3 * tri + 1];
                         i2 = p.indices[3 * tri + 2];
@@ -486,9 +524,46 @@ __global__ __launch_bounds__(kRenderBlock) void render_kernel(const Params p)
                     const v3 N0 = ld3(p.normals, i0), N1 = ld3(p.normals, i1), N2 = ld3(p.normals, i2);
                     N = vnormalize(vadd(vadd(vscale(N0, w0), vscale(N1, bu)), vscale(N2, bv)));
                 }
-                const Pbr m = p.materials[p.tri_material ? p.tri_material[tri] : 0u];
-                const v3 base = mk(m.base_color[0], m.base_color[1], m.base_color[2]);
-                const float metallic = m.metallic * 1.0f, roughness = m.roughness * 1.0f;   // (x the (1,1,1,1) of an absent texture, :270-275)
+                const unsigned int mi = p.tri_material ? p.tri_material[tri] : 0u;
+                const Pbr m = p.materials[mi];
+                v3 base = mk(m.base_color[0], m.base_color[1], m.base_color[2]);
+                float mr_y = 1.0f, mr_z = 1.0f;   // the (1,1,1,1) of an absent metallic-roughness texture, whitted.cu:271
+                if (p.mat_tex) {
+                    const MatTex mt = p.mat_tex[mi];
+                    if (mt.base_color.px || mt.metallic_roughness.px || mt.normal.px) {
+                        // getLocalGeometry's UV and dp/du, dp/dv (LocalGeometry.h:88-135)
+                        float2 UV0 = make_float2(0.0f, 0.0f), UV1 = make_float2(0.0f, 1.0f), UV2 = make_float2(1.0f, 0.0f), UV = make_float2(bu, bv);
+                        if (p.texcoords) {
+                            UV0 = make_float2(p.texcoords[2 * i0], p.texcoords[2 * i0 + 1]);
+                            UV1 = make_float2(p.texcoords[2 * i1], p.texcoords[2 * i1 + 1]);
+                            UV2 = make_float2(p.texcoords[2 * i2], p.texcoords[2 * i2 + 1]);
+                            UV = make_float2(w0 * UV0.x + bu * UV1.x + bv * UV2.x, w0 * UV0.y + bu * UV1.y + bv * UV2.y);
+                        }
+                        if (mt.base_color.px) {
+                            // base_color *= linearize( tex2D ), whitted.cu:78-85, 264-267
+                            const float4 tc = tex2d(mt.base_color, UV.x, UV.y);
+                            base = vmul(base, mk(powf(tc.x, 2.2f), powf(tc.y, 2.2f), powf(tc.z, 2.2f)));
+                        }
+                        if (mt.metallic_roughness.px) {
+                            const float4 tc = tex2d(mt.metallic_roughness, UV.x, UV.y);   // (occlusion, roughness, metallic), :272-276
+                            mr_y = tc.y;
+                            mr_z = tc.z;
+                        }
+                        if (mt.normal.px) {
+                            // whitted.cu:288-292 over LocalGeometry.h:118-134
+                            const float du1 = UV0.x - UV2.x, du2 = UV1.x - UV2.x, dv1 = UV0.y - UV2.y, dv2 = UV1.y - UV2.y;
+                            const v3 dp1 = vsub(P0, P2), dp2 = vsub(P1, P2);
+                            const float det = du1 * dv2 - dv1 * du2;
+                            const float invdet = 1.0f / det;
+                            const v3 dpdu = vscale(vsub(vscale(dp1, dv2), vscale(dp2, dv1)), invdet);
+                            const v3 dpdv = vscale(vadd(vscale(dp1, -du2), vscale(dp2, du1)), invdet);
+                            const float4 tc = tex2d(mt.normal, UV.x, UV.y);
+                            const float nx = 2.0f * tc.x - 1.0f, ny = 2.0f * tc.y - 1.0f, nz = 2.0f * tc.z - 1.0f;
+                            N = vnormalize(vadd(vadd(vscale(vnormalize(dpdu), nx), vscale(vnormalize(dpdv), ny)), vscale(N, nz)));
+                        }
+                    }
+                }
+                const float metallic = m.metallic * mr_z, roughness = m.roughness * mr_y;   // :269-276
                 const float F0 = 0.04f;
                 const v3 diff_color = vscale(vscale(base, 1.0f - F0), 1.0f - metallic);
                 // lerp(a, b, t) = a + t * (b - a), vec_math.h:496-499
@@ -569,7 +644,8 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
                                                               float4* __restrict__ recs, float4* __restrict__ tris, uint4* __restrict__ qrecs,
                                                               uint2* __restrict__ tidx, int* __restrict__ out_meta)
 {
-    __shared__ unsigned long long s_keys[kMaxTriangles];
+    extern __shared__ __attribute__((aligned(16))) unsigned char build_keys_dyn[];   // kMaxTriangles x 8 B: the launch passes the size
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(build_keys_dyn);
     __shared__ float s_red[6][kBuildThreads];
     __shared__ int s_depth, s_nrec, s_wdepth;
     const int tid = threadIdx.x;
@@ -731,7 +807,7 @@ __global__ __launch_bounds__(kBuildThreads) void build_kernel(const float* __res
     }
     auto link_of = [&](int child) -> int {
         if (child >= leaf0) return -1 - (child - leaf0);                                         // one triangle
-        if (count_of[child] <= kLeafTris) return -1 - (first_of[child] | ((count_of[child] - 1) << 12));
+        if (count_of[child] <= kLeafTris) return -1 - (first_of[child] | ((count_of[child] - 1) << kLeafShift));
         return rec_of[child];
     };
     for (int i = tid; i < n - 1; i += kBuildThreads) {
@@ -835,7 +911,7 @@ __global__ __launch_bounds__(kBuildThreads) void sah_kernel(int n, const float4*
         u_box[u][0] = b0.x; u_box[u][1] = b0.y; u_box[u][2] = b0.z;
         u_box[u][3] = b1.x; u_box[u][4] = b1.y; u_box[u][5] = b1.z;
         const int first = k >= leaf0 ? k - leaf0 : first_of[k], cnt = k >= leaf0 ? 1 : count_of[k];
-        u_link[u] = -1 - (first | ((cnt - 1) << 12));
+        u_link[u] = -1 - (first | ((cnt - 1) << kLeafShift));
         u_w[u] = (unsigned char)cnt;
         perm[u] = (short)u;
     }

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(capi):
     L = capi.load()
     for n in names:
         assert getattr(L, n) is not None
-    assert L.rtgo_abi_version() == 4
+    assert L.rtgo_abi_version() == 5
 
 
 def test_host_header_symbols_are_exported(capi):

@@ -1082,6 +1082,10 @@ def test_assemble_bands_odd_shapes(capi):
 def _whitted_ctx(capi, mesh, cam, W, H):
     ctx = capi.Context(0)
     ctx.whitted_set_mesh(mesh["positions"], mesh.get("normals"), mesh["indices"], mesh.get("tri_material"), mesh["materials"])
+    if mesh.get("texcoords") is not None:
+        ctx.whitted_set_texcoords(mesh["texcoords"])
+    for mi, (bc, mr, nm) in (mesh.get("textures") or {}).items():
+        ctx.whitted_set_material_textures(mi, bc, mr, nm)
     ctx.whitted_set_lights(mesh["lights"])
     ctx.whitted_set_miss_color(mesh["miss"])
     ctx.set_camera(cam[0:3], cam[3:6], cam[6:9], cam[9:12])
@@ -1236,7 +1240,7 @@ def test_whitted_edge_cases(capi, oracle):
         ctx.whitted_launch(W, H, 0)                                          # no mesh
     with pytest.raises(capi.RtgoError):
         ctx.whitted_set_mesh(one["positions"], None, np.array([[0, 1, 3]], np.uint32), None, one["materials"])    # index beyond the vertices
-    big = np.zeros((4097, 3), np.uint32)
+    big = np.zeros((8193, 3), np.uint32)
     with pytest.raises(capi.RtgoError):
         ctx.whitted_set_mesh(one["positions"], None, big, None, one["materials"])                                # too many triangles
     with pytest.raises(capi.RtgoError):
@@ -1266,3 +1270,39 @@ def test_whitted_coincident_triangles(capi, oracle):
     racc, rimg, _ = oracle.whitted_render(mesh, cam, W, H, 2)
     assert_parity(ctx.read_accum(H, W), racc, ctx.read_image(H, W), rimg, what="coincident triangles")
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["waterbottle", "quads", "quads_barycentric_uv"])
+def test_whitted_textures_against_the_oracle(capi, oracle, variant, monkeypatch):
+    """the three tex2D branches of __closesthit__radiance (whitted.cu:264-292: base colour with linearize, metallic-roughness, normal map
+    over dp/du, dp/dv of LocalGeometry.h:118-134) and getLocalGeometry's UV (:88-102): the reference's own asset data/WaterBottle (4510
+    triangles: past round 2's cap of 4096; fixture by tests/golden/waterbottle/make_fixture.py), and procedural quads whose texture
+    coordinates wrap on both sides under textures of odd size, with and without per-vertex coordinates.  Against the oracle at 1e-4;
+    the three residency modes give one frame bit for bit."""
+    import whitted_scene
+    W, H = (160, 120) if variant == "waterbottle" else (96, 72)
+    if variant == "waterbottle":
+        mesh = whitted_scene.waterbottle()
+        cam = whitted_scene.camera(oracle, W, H, eye=(0.12, 0.08, 0.42), lookat=(0.0, 0.0, 0.0), fov=40.0)
+    else:
+        mesh = whitted_scene.textured_quad(with_texcoords=variant == "quads")
+        cam = whitted_scene.camera(oracle, W, H, eye=(0.3, 1.4, 5.0), lookat=(0.0, 0.9, -1.0), fov=45.0)
+    frames = {}
+    for mode in ("2", "1", "0"):
+        monkeypatch.setenv("RTGO_WHITTED_MODE", mode)
+        ctx = _whitted_ctx(capi, mesh, cam, W, H)
+        for sf in range(2):
+            ctx.whitted_launch(W, H, sf)
+        ctx.sync()
+        frames[mode] = (ctx.read_accum(H, W).copy(), ctx.read_image(H, W).copy(), ctx.stats())
+        ctx.close()
+    monkeypatch.delenv("RTGO_WHITTED_MODE", raising=False)
+    for mode in ("1", "0"):
+        assert np.array_equal(frames["2"][0].view(np.uint32), frames[mode][0].view(np.uint32)), (variant, mode)
+    racc, rimg, rc = oracle.whitted_render(mesh, cam, W, H, 2)
+    m = assert_parity(frames["2"][0], racc, frames["2"][1], rimg, what="whitted textures " + variant)
+    assert frames["2"][2]["rays_total"] == rc["rays_total"]
+    on = (racc[..., :3] != np.float32(mesh["miss"])).any(axis=-1)
+    assert on.mean() > 0.1 and racc[on][:, :3].mean() > 0.01     # (the mesh is in view and shaded: the comparison is not background against background)
+    print("whitted textures", variant, m)

@@ -75,3 +75,48 @@ def test_committed_whitted_render_reproduces_bitwise(oracle):
     acc, img, c = oracle.whitted_render(mesh, cam, W, H, 2)
     assert np.array_equal(acc.view(np.uint32), z["accum"].view(np.uint32)) and np.array_equal(img, z["image"])
     assert [c["rays_total"], c["rays_occlusion"]] == z["rays"].tolist()
+
+
+def test_tex2d_known_answers(oracle):
+    """tex2D<float4> as the CUDA programming guide states linear filtering, on the texture objects of sutil::Scene::addSampler
+    (normalised coordinates and reads, wrap addressing -- whatever the glTF sampler says: Scene.cpp:517-524 compares CUDA enums with GL
+    constants): texel centres return the texel, halfway between two the mean, (0, 0) the mean of the four corners of a 2 x 2 image
+    (wrap), the result is periodic, and the weights have 8 fractional bits"""
+    t = np.zeros((2, 2, 4), np.uint8)
+    t[0, 0], t[0, 1], t[1, 0], t[1, 1] = [255, 0, 0, 255], [0, 255, 0, 255], [0, 0, 255, 255], [255, 255, 255, 255]
+    assert oracle.tex2d(t, 0.25, 0.25).tolist() == [1.0, 0.0, 0.0, 1.0]
+    assert oracle.tex2d(t, 0.75, 0.25).tolist() == [0.0, 1.0, 0.0, 1.0]
+    assert oracle.tex2d(t, 0.25, 0.75).tolist() == [0.0, 0.0, 1.0, 1.0]
+    assert oracle.tex2d(t, 0.5, 0.25).tolist() == [0.5, 0.5, 0.0, 1.0]
+    assert oracle.tex2d(t, 0.0, 0.0).tolist() == [0.5, 0.5, 0.5, 1.0]
+    for du, dv in ((1.0, 0.0), (-2.0, 3.0)):
+        assert np.array_equal(oracle.tex2d(t, 0.3 + du, 0.6 + dv), oracle.tex2d(t, 0.3, 0.6))
+    # 1.8 fixed point: moving u by less than half a weight step changes nothing; the weight moves in steps of 1/256
+    g = np.zeros((1, 2, 4), np.uint8)
+    g[0, 1] = 255
+    base = float(oracle.tex2d(g, 0.25 + 0.5 * 100 / 256, 0.5)[0])
+    assert base == 100 / 256
+    assert float(oracle.tex2d(g, 0.25 + 0.5 * 100.4 / 256, 0.5)[0]) == base
+    assert float(oracle.tex2d(g, 0.25 + 0.5 * 101 / 256, 0.5)[0]) == 101 / 256
+
+
+def test_waterbottle_fixture_and_its_render(oracle):
+    """the reference's triangle asset through the oracle: the fixture is what the glTF says (2549 vertices, 4510 triangles, unit normals,
+    texture coordinates in [0, 1]), textures change the picture, and the normal map changes it again"""
+    mesh = whitted_scene.waterbottle()
+    assert mesh["positions"].shape == (2549, 3) and mesh["indices"].shape == (4510, 3) and mesh["indices"].max() == 2548
+    assert np.allclose(np.linalg.norm(mesh["normals"], axis=1), 1.0, atol=1e-3)
+    assert mesh["texcoords"].min() >= 0.0 and mesh["texcoords"].max() <= 1.0
+    assert abs(mesh["positions"][:, 1]).max() < 0.14 and mesh["textures"][0][0].shape == (256, 256, 4)
+    W, H = 64, 48
+    cam = whitted_scene.camera(oracle, W, H, eye=(0.12, 0.08, 0.42), lookat=(0.0, 0.0, 0.0), fov=40.0)
+    full, _, rc = oracle.whitted_render(mesh, cam, W, H, 1)
+    bc, mr, nm = mesh["textures"][0]
+    plain, _, _ = oracle.whitted_render(dict(mesh, textures=None), cam, W, H, 1)
+    no_nm, _, _ = oracle.whitted_render(dict(mesh, textures={0: (bc, mr, None)}), cam, W, H, 1)
+    on = (full[..., :3] != np.float32(mesh["miss"])).any(axis=-1)
+    assert 0.1 < on.mean() < 0.9 and rc["rays_total"] > W * H
+    assert np.abs(full[on] - plain[on]).mean() > 1e-2 and np.abs(full[on] - no_nm[on]).mean() > 1e-4
+    # without texture coordinates UV = the barycentrics (LocalGeometry.h:97-102): another picture, still finite
+    bary, _, _ = oracle.whitted_render(dict(mesh, texcoords=None), cam, W, H, 1)
+    assert np.isfinite(bary).all() and np.abs(bary[on] - full[on]).mean() > 1e-3
