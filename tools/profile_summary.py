@@ -3,7 +3,13 @@ import collections, csv, glob, json, os, sys
 
 d, tag = sys.argv[1], sys.argv[2]
 KERNEL = "render_kernel<true, false"   # any register-budget variant of the timed path-mode kernel
-out = {"tag": tag, "kernel": "rtgo::" + KERNEL, "head": os.environ.get("RTGO_HEAD", "unknown")}   # RTGO_HEAD: the commit the profiled tree is (the GPU box has no .git)
+head = os.environ.get("RTGO_HEAD")   # the commit the profiled tree is (the GPU box has no .git); a re-run of this script keeps what the first run recorded
+if not head:
+    try:
+        head = json.load(open(os.path.join(d, "summary.json"))).get("head")
+    except Exception:
+        head = None
+out = {"tag": tag, "kernel": "rtgo::" + KERNEL, "head": head or "unknown"}
 try:
     out["bench"] = json.loads([l for l in open(os.path.join(d, "bench.json")) if l.startswith("{")][-1])
 except Exception as e:
