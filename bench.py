@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--sample", type=int, default=4)
     ap.add_argument("--mode", default="path", choices=["path", "distributed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--spin-up", type=int, default=100, help="untimed launches into scratch buffers before the warm-up steps (GPU clocks)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the per-frame band gather (diagnostic)")
     ap.add_argument("--launches-per-frame", type=int, default=0, choices=[0, 1, 2],
                     help="a rank renders its share as 1 launch, or as 2 half-share launches on two contexts / HIP streams so that "
@@ -271,6 +272,17 @@ def main():
     Vbar, Tbar, hbar = nodes_s / rays_s, tests_s / rays_s, hits_s / rays_s
     A_ray = 32 + 32 + 32 * Vbar + 64 * Tbar + 40 * hbar
     A_px = 36                                             # frame > 0: float4 read + float4 write + uchar4 write
+
+    # ---- clocks: a GPU that has been idle runs its first milliseconds below its sustained clock, and W = 5 warm-up frames are 5 ms.
+    #      Untimed launches into the scratch buffers first (the accumulation buffer and the frame numbers of the run are untouched),
+    #      so that a short run (--steps 20) measures the same kernel time as a long one and as rocprofv3 does.
+    for i in range(S):
+        bind(i, scratch_a, scratch_i)
+    for k in range(args.spin_up):
+        for i in range(S):
+            ctxs[i].launch(frame(k, i))
+    for c in ctxs:
+        c.sync()
 
     # ---- warmup + timed region
     for f in range(args.warmup):
