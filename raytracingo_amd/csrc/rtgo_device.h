@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     unsigned long long tl_t1 = 0, tl_first = 0, tl_lanes = 0, tl_qwait = 0, tl_cold = 0;
     unsigned int tl_hot = 0;
     unsigned long long tl_a = 0, tl_b = 0, tl_c = 0, tl_d = 0, tl_big = 0, tl_tree = 0, tl_loop = 0;
+    unsigned long long tls_regen = 0, tls_trace = 0, tls_shade = 0, tls_lanes_trace = 0, tls_lanes_regen = 0, tls_regens = 0;   // streaming loop (tools/timeline_stream.py)
     unsigned int tl_units = 0, tl_iters = 0;
 #endif
     if (STATS) {
@@ -1337,7 +1338,14 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                 lvA[q] = mk(0, 0, 0);
                 lvPrim[q] = 0;
             }
+#ifdef RTGO_TIMELINE
+            unsigned long long ts_regen = 0, ts_trace = 0, ts_shade = 0, ts_fold = 0, ts_lanes_trace = 0, ts_lanes_regen = 0, ts_regens = 0;
+#endif
             while (fold_ptr < n_tasks) {
+#ifdef RTGO_TIMELINE
+                const unsigned long long ts0 = wall_clock64();
+                tl_iters += 1;
+#endif
                 // ---- idle lanes take the next tasks, in lane order
                 const unsigned long long m_idle = __builtin_amdgcn_ballot_w64(!active), m_act = ~m_idle;
                 const unsigned int room = kRing - (t_next - fold_ptr);
@@ -1359,16 +1367,29 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
 #include "rtgo_start_sample.inc"
                     }
                     t_next += n_take;
+#ifdef RTGO_TIMELINE
+                    ts_lanes_regen += n_take;
+                    ts_regens += 1;
+#endif
                 }
-                // ---- one ray for every lane that has a path
-                if (__builtin_amdgcn_ballot_w64(active) != 0ull) {
+#ifdef RTGO_TIMELINE
+                const unsigned long long ts1 = wall_clock64() + (seed == 0x12345u ? 1 : 0);
+                ts_regen += ts1 - ts0;
+                unsigned long long ts3 = ts1;
+#endif
+                const bool run = active;
+                // ---- one ray for every lane that runs
+                if (__builtin_amdgcn_ballot_w64(run) != 0ull) {
+#ifdef RTGO_TIMELINE
+                    ts_lanes_trace += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(run));
+#endif
 #ifdef RTGO_STREAM_STATS
                     ss_iter += 1;
                     ss_trace += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(active));
                     if (room == 0u && m_idle != 0ull && t_next < n_tasks) ss_stall += 1;
 #endif
-                    const bool was = active;
-                    if (active) {
+                    const bool was = run;
+                    if (run) {
 #include "rtgo_ray_trace.inc"
 #ifdef RTGO_STREAM_STATS
                         if (__builtin_amdgcn_ballot_w64(hit) != 0ull) {
@@ -1383,6 +1404,10 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         s_ring[2u * kRing + my_slot] = result.z;
                         s_ring[my_slot] = result.x;
                     }
+#ifdef RTGO_TIMELINE
+                    ts3 = wall_clock64() + (result.x == 12345.0f ? 1 : 0);
+                    ts_trace += ts3 - ts1;   // (trace + shading + the ring write of this iteration)
+#endif
                 }
                 // ---- the completed prefix of the task list goes into the pixels
                 {
@@ -1402,7 +1427,14 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
                         fold_ptr += n_ready;
                     }
                 }
+#ifdef RTGO_TIMELINE
+                ts_shade += wall_clock64() + (color.x == 12345.0f ? 1 : 0) - ts3;   // (the fold of the completed prefix)
+#endif
             }
+#ifdef RTGO_TIMELINE
+            tls_regen += ts_regen; tls_trace += ts_trace; tls_shade += ts_shade; tls_lanes_trace += ts_lanes_trace; tls_lanes_regen += ts_lanes_regen; tls_regens += ts_regens;
+            tl_units += 1;
+#endif
             if ((unsigned int)lane < npx) write_pixel(p, (size_t)lr * p.w + strip_x0 + ui * P + (unsigned int)lane, vscale(color, 1.0f / (float)nn));
         }
 
@@ -1421,6 +1453,9 @@ __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, 
     if (lane == 0) {
         unsigned long long* r = p.timeline + 16ull * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
         r[8] = tl_a; r[9] = tl_b; r[10] = tl_c; r[11] = tl_d; r[12] = tl_big; r[13] = tl_tree; r[14] = tl_loop;
+        if constexpr (STREAM) {
+            r[8] = tls_regen; r[9] = tls_trace; r[10] = tls_shade; r[11] = tls_lanes_trace; r[14] = tls_regens; r[15] = tls_lanes_regen;
+        }
         r[0] = tl_t0; r[1] = tl_t1; r[2] = tl_first; r[3] = wall_clock64(); r[4] = tl_units | ((unsigned long long)tl_hot << 32); r[5] = tl_iters; r[6] = tl_lanes;
         r[7] = tl_qwait | ((tl_cold ? tl_cold - tl_t0 : 0ull) << 32);
     }
