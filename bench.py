@@ -389,6 +389,8 @@ def main():
                                                "counted_over": "traversed rays (instrumented canonical-LBVH launch with the timed kernel's background culling)",
                                                "bytes_per_launch": int(ray_bytes),
                                                "rate_GBps": round(ray_bytes / kernel_s / 1e9, 1) if kernel_s > 0 else 0.0,
+                                               # SURVEY 8d's floor: 32 + 32 + 64 + 40 = 168 B per ray (one primitive test, no nodes)
+                                               "A_ray_min_bytes": 168, "rate_min_GBps": round(trav_per_launch * 168.0 / world / kernel_s / 1e9, 1) if kernel_s > 0 else 0.0,
                                                "served_from": "LDS and the scalar cache (not HBM): SURVEY 8d's byte model priced on the canonical LBVH's counts, which the timed kernel does not walk -- a workload description, not an achieved rate of this kernel"},
                          "note": "frac is small by design: the kernel is bound by vector issue (binding), not by HBM"},
         }
