@@ -37,12 +37,27 @@ struct rtgo_ctx {
     // 4.42 ms against 4.9).  Which one is faster is a property of scene and frame that the host cannot see, but the launch times
     // it takes anyway tell: the first four launches of a (scene, frame geometry, spp, mode) alternate between the two, the faster
     // minimum keeps the job.
+    // Round 3: the same trial also decides WHICH fast-walk structure a launch walks.  How big a primitive has to be to be tested up
+    // front by every ray instead of sitting in the tree (build_kernel's big_frac) is worth 20 % on plateau (nearly everything up front:
+    // a dozen tests at full lanes beat a walk at a third of them) and costs 20 % on cornell (its two boxes lose their cuboid leaves), and
+    // no rule read off the scene predicts it (profiles/r03n/big_sweep.log); so rtgo_set_scene builds the structure twice -- 36 % and 15 % --
+    // and the candidates of a trial are (loop, structure) pairs: every candidate gets two timed launches, the best minimum keeps the job.
+    // All candidates return the same pixels bit for bit (any tree over the same primitives returns the same closest hit).
     struct Trial {
         std::vector<uint32_t> key;
         int issued = 0, done = 0;
-        float best[2] = {1e30f, 1e30f};
-        int choice = -1;                   // 0 = streaming, 1 = lock-step, -1 = undecided
+        int n_cand = 0;
+        float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+        int choice = -1;                   // index of the winning candidate, -1 = undecided
     } trial;
+    struct FastTree {                      // what build_kernel makes for one big_frac (see the fields of the same names below)
+        float4* d_fnodes = nullptr;
+        float4* d_fprims = nullptr;
+        int fast_depth = 0, n_small = 0, n_fnodes = 0, cuboid_groups = 0, tree_spheres = 0, list_cub = 0, n_big_pairs = 0;
+        float cub_a = 0.0f, cub_b = 0.0f;
+    } alt;                                 // the second structure (15 %); the first one lives in the fields below
+    bool have_alt = false;                 // false: the two builds came out the same, or RTGO_BIG_PERCENT pins one
+    int* d_meta_alt = nullptr;
     // scene
     uint32_t n_prims = 0;
     PrimIn* d_prims_in = nullptr;
@@ -202,7 +217,7 @@ static int harvest_events(rtgo_ctx* c, int count)
         c->total_ms += ms;
         c->ev_pending--;
         if (c->ev_tag[slot] != 0) {
-            float& best = c->trial.best[c->ev_tag[slot] - 1];
+            float& best = c->trial.best[(c->ev_tag[slot] - 1) & 3];
             best = ms < best ? ms : best;
             c->trial.done++;
             c->ev_tag[slot] = 0;
@@ -406,6 +421,9 @@ int rtgo_destroy(rtgo_ctx* c)
     (void)hipFree(c->d_prims);
     (void)hipFree(c->d_fnodes);
     (void)hipFree(c->d_fprims);
+    (void)hipFree(c->alt.d_fnodes);
+    (void)hipFree(c->alt.d_fprims);
+    (void)hipFree(c->d_meta_alt);
     (void)hipFree(c->d_frames);
     (void)hipFree(c->d_meta);
     (void)hipFree(c->d_lights);
@@ -488,6 +506,10 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     (void)hipFree(c->d_prims);
     (void)hipFree(c->d_fnodes);
     (void)hipFree(c->d_fprims);
+    (void)hipFree(c->alt.d_fnodes);
+    (void)hipFree(c->alt.d_fprims);
+    c->alt = rtgo_ctx::FastTree();
+    c->have_alt = false;
     (void)hipFree(c->d_frames);
     (void)hipFree(c->d_tight);
     c->d_frames = nullptr;
@@ -538,6 +560,32 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     if (c->n_fnodes < 0 || c->n_fnodes > 2 * (int)n - 1 || (c->n_small > 0 && c->n_fnodes < 1))
         return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: the fast walk's tree has " + std::to_string(c->n_fnodes) + " nodes");
     std::memcpy(c->bounds, &meta[3], sizeof c->bounds);
+    if (!std::getenv("RTGO_BIG_PERCENT") && !std::getenv("RTGO_ONE_TREE")) {
+        // the alternative structure: big_frac 15 % (the canonical outputs, boxes and frames are rewritten with the same values)
+        RTGO_HIP(c, hipMalloc(&c->alt.d_fnodes, (2 * n - 1) * 2 * sizeof(float4)));
+        RTGO_HIP(c, hipMalloc(&c->alt.d_fprims, n * 4 * sizeof(float4)));
+        if (!c->d_meta_alt) RTGO_HIP(c, hipMalloc(&c->d_meta_alt, 16 * sizeof(int)));
+        hipLaunchKernelGGL(build_kernel, dim3(1), dim3(kMaxPrims), kBuildDynLds, c->stream, c->d_prims_in, c->d_aabb, 1, (int)n,
+                           c->d_nodes, c->d_prims, c->alt.d_fnodes, c->alt.d_fprims, c->leaf_budget, 0.15f, c->d_meta_alt, c->d_tight,
+                           std::getenv("RTGO_NO_CUBOID") ? 0 : 1, c->d_frames);
+        RTGO_HIP(c, hipGetLastError());
+        int m2[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        RTGO_HIP(c, hipMemcpyAsync(m2, c->d_meta_alt, sizeof m2, hipMemcpyDeviceToHost, c->stream));
+        RTGO_HIP(c, hipStreamSynchronize(c->stream));
+        rtgo_ctx::FastTree& a = c->alt;
+        a.fast_depth = m2[1];
+        a.n_small = m2[2];
+        a.n_big_pairs = m2[9] & 0xFF;
+        a.list_cub = m2[9] >> 8;
+        a.cuboid_groups = m2[13] + (a.list_cub ? 1 : 0);
+        a.tree_spheres = (a.n_small > 0 && m2[14] == (1 << 3) && !std::getenv("RTGO_NO_SPHERE_LEAVES")) ? 1 : 0;
+        std::memcpy(&a.cub_a, &m2[11], sizeof(float));
+        std::memcpy(&a.cub_b, &m2[12], sizeof(float));
+        a.n_fnodes = m2[10];
+        const bool sane = m2[0] == meta[0] && a.n_fnodes >= 0 && a.n_fnodes <= 2 * (int)n - 1 && !(a.n_small > 0 && a.n_fnodes < 1);
+        // (the same split of primitives = the same structure: nothing to try)
+        c->have_alt = sane && !(a.n_small == c->n_small && a.n_fnodes == c->n_fnodes && a.n_big_pairs == c->n_big_pairs && a.list_cub == c->list_cub);
+    }
     if (std::getenv("RTGO_DEBUG"))
         std::fprintf(stderr, "rtgo_set_scene: %d primitives, %d in the fast walk's tree (%d nodes, depth %d), %d up front (%d pairs, cuboid certificate %d), %d cuboid leaves, margin coefficients %g %g, canonical LBVH depth %d\n",
                      (int)n, c->n_small, c->n_fnodes, c->fast_depth, (int)n - c->n_small, c->n_big_pairs, c->list_cub, meta[13], c->cub_a, c->cub_b, depth);
@@ -723,14 +771,78 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
         c->guard_quadric = quad;
         static const float guard_reach_max = env_float("RTGO_GUARD_REACH", kGuardReach), guard_quadric_max = env_float("RTGO_GUARD_QUADRIC", kGuardQuadric);
         if (!(reach <= guard_reach_max) || !(quad <= guard_quadric_max)) canon = true;
+    }
+    // ---- which loop and which structure (rtgo_ctx::Trial).  More than 16 spp = several passes per pixel: the streaming variant
+    // (render_kernel, STREAM) lets a lane start its next sample when its path has ended instead of waiting for the wave's longest path,
+    // pass after pass; and where rtgo_set_scene's two builds differ, either structure can be the faster one.  Candidate k = loop (k & 1:
+    // 0 = streaming when there is a choice) | structure (k >> 1 when both loops are candidates, else k).
+    bool stream = false, use_alt = false;
+    unsigned char trial_tag = 0;
+    if (!canon) {
+        const bool multi_pass = passes_of(nn) > 1;
+        const char* force_loop = std::getenv("RTGO_STREAM");   // "0" / "1": experiment and test knobs, no trial over that dimension
+        const char* force_tree = std::getenv("RTGO_TREE");     // "0" / "1": the 36 % / the 15 % structure
+        const bool loops = multi_pass && !force_loop, trees = c->have_alt && !force_tree;
+        if (multi_pass && force_loop) stream = force_loop[0] != '0';
+        if (c->have_alt && force_tree) use_alt = force_tree[0] == '1';
+        const int n_cand = (loops ? 2 : 1) * (trees ? 2 : 1);
+        auto decode = [&](int k) {
+            if (loops) stream = (k & 1) == 0;
+            if (trees) use_alt = ((loops ? k >> 1 : k) & 1) != 0;
+        };
+        if (n_cand > 1) {
+            rtgo_ctx::Trial& t = c->trial;
+            const std::vector<uint32_t> key = {p.W, p.H, p.x0, p.y0, p.w, p.h, p.band_h, p.n_ranks, p.rank, nn, (uint32_t)path, (uint32_t)f->max_trace_depth,
+                                               (uint32_t)(f->use_ambient != 0), (uint32_t)n_cand, (uint32_t)stream, (uint32_t)use_alt};
+            if (key != t.key) {
+                // (event tags of an unfinished trial of the old key stay where they are: they are counted into the old minima nobody reads)
+                t = rtgo_ctx::Trial();
+                t.key = key;
+                t.n_cand = n_cand;
+                for (unsigned char& tag : c->ev_tag) tag = 0;
+            }
+            if (t.choice < 0 && t.issued >= 2 * n_cand) {
+                // all are in flight or done: take what has finished, without waiting
+                while (c->ev_pending > 0) {
+                    const int slot = (c->ev_head - c->ev_pending + 2 * rtgo_ctx::kEvRing) % rtgo_ctx::kEvRing;
+                    if (hipEventQuery(c->ev_stop[slot]) != hipSuccess) break;
+                    const int rc = harvest_events(c, 1);
+                    if (rc) return rc;
+                }
+                (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error of this launch)
+                if (t.done >= 2 * n_cand) {
+                    t.choice = 0;
+                    for (int k = 1; k < n_cand; ++k)
+                        if (t.best[k] < t.best[t.choice]) t.choice = k;
+                }
+            }
+            if (t.choice >= 0) decode(t.choice);
+            else if (t.issued < 2 * n_cand) {
+                const int k = t.issued % n_cand;
+                decode(k);
+                trial_tag = (unsigned char)(k + 1);
+                t.issued++;
+            } else decode(0);   // results pending
+        }
+    }
+    // the structure this launch walks
+    const rtgo_ctx::FastTree ft = use_alt ? c->alt : [&] {
+        rtgo_ctx::FastTree m;
+        m.d_fnodes = c->d_fnodes; m.d_fprims = c->d_fprims; m.fast_depth = c->fast_depth; m.n_small = c->n_small; m.n_fnodes = c->n_fnodes;
+        m.cuboid_groups = c->cuboid_groups; m.tree_spheres = c->tree_spheres; m.list_cub = c->list_cub; m.n_big_pairs = c->n_big_pairs;
+        m.cub_a = c->cub_a; m.cub_b = c->cub_b;
+        return m;
+    }();
+    {
+        float reach = c->guard_reach;
         // cuboid_range's margin, in the object-space y units of a face g: the certificate's tolerance plus the rounding of what is
         // compared -- the reference's (u, v) on a face f, carried into y_g units by L_fg, and y_g(t_f) itself.  Each is a handful of
         // float operations on terms no larger than |row| (|o| + t |d|) + |w| <= |row|_1 * 3 reach + |w| (origins within `reach`, hit
         // points within the scene: t |d| <= 2 reach), i.e. <= 12 * 2^-24 of them; K = 64 * 2^-24 leaves five times that, and the
         // build's A, B = max over (f, g) of L_fg |row_f|_1 + |row_g|_1 and of L_fg |w_f| + |w_g|.
-        p.cub_mu = kCuboidTol + 64.0f * 5.9604645e-8f * (c->cub_a * 3.0f * reach + c->cub_b);
-        p.list_cub = c->list_cub;
-        p.tree_spheres = c->tree_spheres;
+        p.cub_mu = kCuboidTol + 64.0f * 5.9604645e-8f * (ft.cub_a * 3.0f * reach + ft.cub_b);
+        p.list_cub = ft.list_cub;
+        p.tree_spheres = ft.tree_spheres;
         if (!(p.cub_mu < 0.02f)) {   // (tiny faces far from the origin: the margin would let two faces through too often to pay)
             p.list_cub = 0;
             p.cub_mu = -1.0f;        // tree leaves: cuboid_range is not taken either (see render_kernel)
@@ -860,13 +972,13 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
-    p.fnodes = c->d_fnodes;
-    p.n_fnodes = c->n_fnodes;
-    p.fprims = c->d_fprims;
+    p.fnodes = ft.d_fnodes;
+    p.n_fnodes = ft.n_fnodes;
+    p.fprims = ft.d_fprims;
     p.frames = c->d_frames;
-    p.n_small = c->n_small;
-    p.n_big_pairs = c->n_big_pairs;
-    p.stack_depth = canon ? kStackDepth : (c->fast_depth > 0 ? c->fast_depth : 1) + 1;   // (+1: fast_tree writes the slot past the top before it knows whether it pushes)
+    p.n_small = ft.n_small;
+    p.n_big_pairs = ft.n_big_pairs;
+    p.stack_depth = canon ? kStackDepth : (ft.fast_depth > 0 ? ft.fast_depth : 1) + 1;   // (+1: fast_tree writes the slot past the top before it knows whether it pushes)
     p.lights = c->d_lights;
     p.accum = c->d_accum;
     p.image = c->d_image;
@@ -898,7 +1010,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
     // The scene copy is per workgroup and the stack per lane, so bigger scenes want bigger workgroups: pick the size that
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
-    const int fast_nodes = c->n_fnodes;
+    const int fast_nodes = ft.n_fnodes;
     frames = path && !canon && c->quadrics.empty() && !std::getenv("RTGO_NO_FRAMES");   // scenes of flat primitives only: N and the sampling tangent from LDS
     const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims + (frames ? 2 * p.n_prims : 0) /* shading frames */) * sizeof(float4) +
                              (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float) +   // + the raygen constants
@@ -915,41 +1027,6 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int max_wpe_work = units_per_wave4 >= 3 ? 5 : 4;
     int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);   // (experiment knob, clamped to what exists)
     max_wpe = max_wpe < 4 ? 4 : (max_wpe > 5 ? 5 : max_wpe);
-    // more than 16 spp = several passes per pixel: the streaming variant (render_kernel, STREAM) lets a lane start its next sample when
-    // its path has ended instead of waiting for the wave's longest path, pass after pass
-    bool stream = false;
-    unsigned char trial_tag = 0;
-    if (!canon && passes_of(nn) > 1) {
-        const char* force = std::getenv("RTGO_STREAM");   // "0" / "1": experiment and test knob, no trial
-        if (force) stream = force[0] != '0';
-        else {
-            rtgo_ctx::Trial& t = c->trial;
-            const std::vector<uint32_t> key = {p.W, p.H, p.x0, p.y0, p.w, p.h, p.band_h, p.n_ranks, p.rank, nn, (uint32_t)path, (uint32_t)f->max_trace_depth, (uint32_t)(f->use_ambient != 0)};
-            if (key != t.key) {
-                // (event tags of an unfinished trial of the old key stay where they are: they are counted into the old minima nobody reads)
-                t = rtgo_ctx::Trial();
-                t.key = key;
-                for (unsigned char& tag : c->ev_tag) tag = 0;
-            }
-            if (t.choice < 0 && t.issued >= 4) {
-                // all four are in flight or done: take what has finished, without waiting
-                while (c->ev_pending > 0) {
-                    const int slot = (c->ev_head - c->ev_pending + 2 * rtgo_ctx::kEvRing) % rtgo_ctx::kEvRing;
-                    if (hipEventQuery(c->ev_stop[slot]) != hipSuccess) break;
-                    const int rc = harvest_events(c, 1);
-                    if (rc) return rc;
-                }
-                (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error of this launch)
-                if (t.done >= 4) t.choice = t.best[0] <= t.best[1] ? 0 : 1;
-            }
-            if (t.choice >= 0) stream = t.choice == 0;
-            else if (t.issued < 4) {
-                stream = (t.issued & 1) == 0;
-                trial_tag = stream ? 1 : 2;
-                t.issued++;
-            } else stream = true;   // results pending
-        }
-    }
     for (int w = 4; w <= max_wpe; ++w)
         for (int b = 256; b <= kMaxBlock; b *= 2) {
             const size_t l = scene_lds + (stream ? (size_t)(b / 64) * 192 * kStreamWindow * sizeof(float) : 0) + (size_t)p.stack_depth * b * (canon ? sizeof(float2) : sizeof(unsigned int)) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
@@ -985,7 +1062,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int slot = c->ev_head;
     c->ev_tag[slot] = trial_tag;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
-    const float4* fp = (const float4*)c->d_fprims;
+    const float4* fp = (const float4*)ft.d_fprims;
     const RenderKernel kernel = find_kernel(path, canon, wpe, stream, stats, frames);
     if (!kernel) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: no kernel variant for this configuration");
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, c->stream, p, fp);

@@ -1306,3 +1306,26 @@ def test_whitted_textures_against_the_oracle(capi, oracle, variant, monkeypatch)
     on = (racc[..., :3] != np.float32(mesh["miss"])).any(axis=-1)
     assert on.mean() > 0.1 and racc[on][:, :3].mean() > 0.01     # (the mesh is in view and shaded: the comparison is not background against background)
     print("whitted textures", variant, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ALL_SCENES)
+def test_the_two_fast_structures_and_the_trial_are_bitwise_the_same(capi, oracle, name, monkeypatch):
+    """rtgo_set_scene builds the fast walk's structure twice (a primitive is tested up front by every ray from 36 % / from 15 % of the scene's
+    extent on two axes) and the first launches of a (frame geometry, spp, mode) try the candidates -- structure x loop -- and keep the fastest
+    (rtgo_ctx::Trial).  Whatever runs, the frame is the canonical walk's bit for bit: RTGO_TREE pins either structure, no pin lets the trial
+    run through its candidates and settle (12 launches)."""
+    W, H = 192, 108
+    sc, t, ctx = upload(capi, oracle, name, W, H)
+    for n, path in ((2, True), (5, True), (3, False)):
+        canon, cimg = gpu_render(capi, ctx, W, H, n, 1, path, stats=True, prev=np.full((H, W, 4), 0.5, np.float32))
+        for pin in ("0", "1", None):
+            if pin is None:
+                monkeypatch.delenv("RTGO_TREE", raising=False)
+            else:
+                monkeypatch.setenv("RTGO_TREE", pin)
+            for rep in range(12 if pin is None else 1):
+                acc, img = gpu_render(capi, ctx, W, H, n, 1, path, prev=np.full((H, W, 4), 0.5, np.float32))
+                assert np.array_equal(acc.view(np.uint32), canon.view(np.uint32)) and np.array_equal(img, cimg), (name, n, path, pin, rep)
+    monkeypatch.delenv("RTGO_TREE", raising=False)
+    ctx.close()
