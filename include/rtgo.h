@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RTGO_ABI_VERSION 5
+#define RTGO_ABI_VERSION 6
 #define RTGO_MAX_PRIMS 512  /* scene staged whole in LDS (largest reference scene: checkered, 390) */
 #define RTGO_MAX_LIGHTS 10  /* Params::MAX_LIGHTS, engine/params.h:115 */
 
@@ -110,6 +110,10 @@ typedef struct rtgo_stats {
     float guard_reach;        /* last launch: max(|scene bounds|, |eye|), world units -- the far-field guard's first quantity */
     float guard_quadric;      /* last launch: max over spheres / cylinders of D^2 smax / smin^2 (D: farthest ray origin -- eye or scene
                                  bounds -- to the primitive; s: its axis scales) -- the guard's second quantity; 0 without quadrics */
+    uint32_t last_variant;    /* last launch: bit 0 streaming loop, bit 1 the second fast-walk structure, bit 2 canonical walk, bit 3 the
+                                 launch was one of the launch-time trial's (the first launches of a job time the candidate
+                                 (loop, structure) pairs -- same pixels either way -- and the fastest keeps the job) */
+    uint32_t launches_trial;  /* launches since rtgo_reset_stats that were trial launches */
 } rtgo_stats;
 
 typedef struct rtgo_ctx rtgo_ctx;

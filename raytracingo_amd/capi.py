@@ -64,7 +64,8 @@ class Stats(C.Structure):
                 ("total_launch_ms", C.c_float), ("launches", C.c_uint32), ("lbvh_depth", C.c_uint32),
                 ("dbg_fast_boxes", C.c_uint64), ("dbg_fast_tests", C.c_uint64), ("rays_culled", C.c_uint64),
                 ("launches_canonical", C.c_uint32), ("cuboid_groups", C.c_uint32),
-                ("guard_reach", C.c_float), ("guard_quadric", C.c_float)]
+                ("guard_reach", C.c_float), ("guard_quadric", C.c_float),
+                ("last_variant", C.c_uint32), ("launches_trial", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -114,6 +114,7 @@ struct rtgo_ctx {
     int queue_set = 0;
     unsigned long long rays_culled = 0;       // since rtgo_reset_stats (host arithmetic: the cold pixels of each launch x N*N)
     uint32_t launches_canonical = 0;          // since rtgo_reset_stats
+    uint32_t launches_trial = 0, last_variant = 0;   // (rtgo_stats)
     unsigned long long* d_counters = nullptr;  // 8 x u64
 #ifdef RTGO_CMPWALK
     float* d_cmp = nullptr;                    // diagnostic build: disagreements between the two walks
@@ -802,14 +803,13 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
                 for (unsigned char& tag : c->ev_tag) tag = 0;
             }
             if (t.choice < 0 && t.issued >= 2 * n_cand) {
-                // all are in flight or done: take what has finished, without waiting
-                while (c->ev_pending > 0) {
-                    const int slot = (c->ev_head - c->ev_pending + 2 * rtgo_ctx::kEvRing) % rtgo_ctx::kEvRing;
-                    if (hipEventQuery(c->ev_stop[slot]) != hipSuccess) break;
+                // all are in flight or done: WAIT for them.  A caller that enqueues a whole job without synchronising (bench.py's spin-up,
+                // a batch render) would otherwise run it to the end on whatever stands in for an undecided trial -- profiles/r03p caught
+                // 90 of 100 launches of C4 on its slowest candidate that way.  One stall of at most 2 * n_cand launches per job.
+                while (t.done < 2 * n_cand && c->ev_pending > 0) {
                     const int rc = harvest_events(c, 1);
                     if (rc) return rc;
                 }
-                (void)hipGetLastError();   // (hipErrorNotReady of the query is not an error of this launch)
                 if (t.done >= 2 * n_cand) {
                     t.choice = 0;
                     for (int k = 1; k < n_cand; ++k)
@@ -1074,6 +1074,8 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     c->ev_pending++;
     c->launches++;
     if (canon) c->launches_canonical++;
+    if (trial_tag) c->launches_trial++;
+    c->last_variant = (stream ? 1u : 0u) | (use_alt ? 2u : 0u) | (canon ? 4u : 0u) | (trial_tag ? 8u : 0u);
     return RTGO_OK;
 }
 
@@ -1435,6 +1437,8 @@ int rtgo_get_stats(rtgo_ctx* c, rtgo_stats* out)
     out->cuboid_groups = (uint32_t)c->cuboid_groups;
     out->guard_reach = c->guard_reach;
     out->guard_quadric = c->guard_quadric;
+    out->last_variant = c->last_variant;
+    out->launches_trial = c->launches_trial;
     return RTGO_OK;
 }
 
@@ -1450,6 +1454,7 @@ int rtgo_reset_stats(rtgo_ctx* c)
     c->last_ms = 0.0f;
     c->launches = 0;
     c->launches_canonical = 0;
+    c->launches_trial = 0;
     c->rays_culled = 0;
     return RTGO_OK;
 }

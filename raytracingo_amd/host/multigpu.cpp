@@ -345,6 +345,8 @@ rtgo_stats MultiGpuRenderer::Stats()
         tot.cuboid_groups = s.cuboid_groups;
         tot.guard_reach = s.guard_reach;       // (the shares see one scene from one eye)
         tot.guard_quadric = s.guard_quadric;
+        tot.last_variant |= s.last_variant;
+        tot.launches_trial += s.launches_trial;
     }
     return tot;
 }

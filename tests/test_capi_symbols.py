@@ -28,7 +28,7 @@ def test_header_symbols_are_exported(capi):
     L = capi.load()
     for n in names:
         assert getattr(L, n) is not None
-    assert L.rtgo_abi_version() == 5
+    assert L.rtgo_abi_version() == 6
 
 
 def test_host_header_symbols_are_exported(capi):
@@ -41,7 +41,7 @@ def test_host_header_symbols_are_exported(capi):
 def test_struct_layouts(capi):
     # rtgo_prim = PRIMITIVE_TYPE + HitGroupData (104 B, params.h:103-110); SurfaceLight 64 B; OptixAabb 24 B
     assert C.sizeof(capi.Prim) == 108 and C.sizeof(capi.Light) == 64 and C.sizeof(capi.Aabb) == 24
-    assert C.sizeof(capi.Frame) == 16 * 4 and C.sizeof(capi.Stats) == 96
+    assert C.sizeof(capi.Frame) == 16 * 4 and C.sizeof(capi.Stats) == 104
     assert capi.Prim.kd.offset == 68 and capi.Prim.Le.offset == 96
 
 

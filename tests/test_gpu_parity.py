@@ -1329,3 +1329,33 @@ def test_the_two_fast_structures_and_the_trial_are_bitwise_the_same(capi, oracle
                 assert np.array_equal(acc.view(np.uint32), canon.view(np.uint32)) and np.array_equal(img, cimg), (name, n, path, pin, rep)
     monkeypatch.delenv("RTGO_TREE", raising=False)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_the_trial_settles_for_a_caller_that_never_synchronises(capi, oracle, monkeypatch):
+    """a job enqueued without a single rtgo_sync (bench.py's spin-up, a batch render) must not run to its end on the stand-in of an undecided
+    trial (profiles/r03p: 90 of 100 launches of mirror_spheres 4K on the slowest candidate): the launch after the 2 x candidates trial launches
+    waits for their times, so launch 2 x candidates + 1 already runs what every later launch runs.  rtgo_stats.last_variant / launches_trial."""
+    monkeypatch.delenv("RTGO_TREE", raising=False)
+    monkeypatch.delenv("RTGO_STREAM", raising=False)
+    W, H = 480, 270
+    sc, t, ctx = upload(capi, oracle, "plateau", W, H)
+    ctx.resize(W * H)
+    fr = capi.make_frame(W, H, 5, 1, True, False, None, (4, 1, 0))          # 25 spp: two passes, so both loops are candidates
+    ctx.reset_stats()
+    for k in range(9):
+        ctx.launch(fr)
+    st = ctx.stats()
+    assert st["launches"] == 9 and st["launches_canonical"] == 0
+    assert st["launches_trial"] in (4, 8), st                             # (4: the two structures came out identical, loops only)
+    n_trial = st["launches_trial"]
+    if n_trial == 4:
+        for k in range(4):
+            ctx.launch(fr)
+    decided = ctx.stats()["last_variant"]
+    assert decided & 8 == 0, "launch 2 x candidates + 1 must be a decided one"
+    for k in range(6):
+        ctx.launch(fr)
+        assert ctx.stats()["last_variant"] == decided
+    assert ctx.stats()["launches_trial"] == n_trial
+    ctx.close()
