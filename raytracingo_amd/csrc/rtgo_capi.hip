@@ -47,9 +47,19 @@ struct rtgo_ctx {
         std::vector<uint32_t> key;
         int issued = 0, done = 0;
         int n_cand = 0;
-        float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+        float best[8] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
         int choice = -1;                   // index of the winning candidate, -1 = undecided
     } trial;
+    // The third structure of the trial: a uniform grid over structure 0's small primitives (rtgo::fast_grid), built by the host from
+    // the boxes build_kernel reports.  Scenes of many small primitives spread evenly (balls: 256 spheres in a room) walk it in a third of
+    // the tree's instructions; where it is slower the trial drops it after two launches.
+    struct Grid {
+        void* d = nullptr;                 // n_cells words (first item | count << 16), then 16-bit items: positions into d_fprims
+        int n_nodes = 0;                   // its size in 32-byte units (what LaunchParams::n_fnodes counts)
+        rtgo::GridParams gp = {};
+        float reach_max = 0.0f;            // the pad of the binning covers the walk's rounding for rays that start within this reach
+        bool have = false;
+    } grid;
     struct FastTree {                      // what build_kernel makes for one big_frac (see the fields of the same names below)
         float4* d_fnodes = nullptr;
         float4* d_fprims = nullptr;
@@ -167,9 +177,11 @@ struct RenderKernelEntry {
     int wpe;
     bool count, frames;
     RenderKernel fn;
+    bool grid = false;
 };
 #define RTGO_K(P, S, W, T) {P, S, T, W, S, false, render_kernel<P, S, W, T>}
 #define RTGO_KF(W, T) {true, false, T, W, false, true, render_kernel<true, false, W, T, false, true>}
+#define RTGO_KG(P, W, T) {P, false, T, W, false, false, render_kernel<P, false, W, T, false, false, true>, true}
 static const RenderKernelEntry kRenderKernels[] = {
     RTGO_K(true, false, 4, false),  RTGO_K(true, false, 5, false),    // path mode, fast walk
     RTGO_K(false, false, 4, false), RTGO_K(false, false, 5, false),   // distributed mode, fast walk
@@ -179,14 +191,17 @@ static const RenderKernelEntry kRenderKernels[] = {
     {true, true, false, 4, false, false, render_kernel<true, true, 4, false, false>},     // canonical walk alone: launches beyond the far-field guard
     {false, true, false, 4, false, false, render_kernel<false, true, 4, false, false>},
     RTGO_KF(4, false), RTGO_KF(5, false), RTGO_KF(4, true), RTGO_KF(5, true),               // path mode, fast walk, scenes of flat primitives only: shading frames from LDS
+    RTGO_KG(true, 4, false), RTGO_KG(true, 5, false), RTGO_KG(true, 4, true), RTGO_KG(true, 5, true),       // fast walk over the uniform grid instead of the tree (fast_grid)
+    RTGO_KG(false, 4, false), RTGO_KG(false, 5, false), RTGO_KG(false, 4, true), RTGO_KG(false, 5, true),
 };
 #undef RTGO_K
 #undef RTGO_KF
-static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream, bool count, bool frames)
+#undef RTGO_KG
+static RenderKernel find_kernel(bool path, bool canon, int wpe, bool stream, bool count, bool frames, bool grid)
 {
     for (const RenderKernelEntry& e : kRenderKernels)
         if (e.path == path && e.canon == canon && e.wpe == (canon ? 4 : wpe) && e.stream == (canon ? false : stream) && e.count == (canon && count) &&
-            e.frames == (frames && path && !canon))
+            e.frames == (frames && path && !canon) && e.grid == (grid && !canon))
             return e.fn;
     return nullptr;
 }
@@ -218,7 +233,7 @@ static int harvest_events(rtgo_ctx* c, int count)
         c->total_ms += ms;
         c->ev_pending--;
         if (c->ev_tag[slot] != 0) {
-            float& best = c->trial.best[(c->ev_tag[slot] - 1) & 3];
+            float& best = c->trial.best[(c->ev_tag[slot] - 1) & 7];
             best = ms < best ? ms : best;
             c->trial.done++;
             c->ev_tag[slot] = 0;
@@ -476,6 +491,106 @@ int rtgo_set_stream(rtgo_ctx* c, void* hip_stream)
     return RTGO_OK;
 }
 
+// The uniform grid of rtgo::fast_grid over structure 0's small primitives (fprims [0, n_small)), from the boxes the fast walk culls
+// with (c->tight: build_kernel's, SBT order).  Every box is grown by `pad` before it is binned, and fast_grid stops `pad / 2` (in t)
+// late: the walk's own rounding (entry point, 96 accumulated steps: <= ~2e-5 of the rays' reach) stays an order of magnitude inside.
+// Cells: ~ lambda per primitive (RTGO_GRID_LAMBDA, default 4), <= 32 per axis, <= 4096; no grid for fewer than 24 small primitives
+// or when the lists come out longer than 8 entries per primitive (a few big shapes among small ones: the tree's job).
+static int build_grid(rtgo_ctx* c, uint32_t n)
+{
+    c->grid.have = false;
+    const int ns = c->n_small;
+    if (ns < 24 || std::getenv("RTGO_NO_GRID")) return RTGO_OK;
+    std::vector<float4> fp((size_t)n * 4);
+    RTGO_HIP(c, hipMemcpyAsync(fp.data(), c->d_fprims, fp.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<const float*> box((size_t)ns);
+    float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f}, scene_reach = 0.0f;
+    for (int pos = 0; pos < ns; ++pos) {
+        int orig;
+        std::memcpy(&orig, &fp[4 * (size_t)pos + 3].y, sizeof orig);
+        if (orig < 0 || orig >= (int)n) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_set_scene: fast-walk record without a primitive");
+        box[pos] = &c->tight[6 * (size_t)orig];
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::fmin(lo[a], box[pos][a]);
+            hi[a] = std::fmax(hi[a], box[pos][3 + a]);
+        }
+    }
+    for (int a = 0; a < 6; ++a) scene_reach = std::fmax(scene_reach, std::fabs(c->bounds[a]));
+    const float reach_max = 4.0f * scene_reach;
+    float ext[3], max_ext = 0.0f;
+    for (int a = 0; a < 3; ++a) {
+        ext[a] = hi[a] - lo[a];
+        max_ext = std::fmax(max_ext, ext[a]);
+    }
+    if (!(max_ext > 0.0f)) return RTGO_OK;
+    // the finest cubic cell whose grid stays within the budget
+    const float lambda = env_float("RTGO_GRID_LAMBDA", 4.0f);
+    const int budget = (int)std::fmin(4096.0f, std::fmax(8.0f, lambda * (float)ns));
+    int dim[3] = {1, 1, 1};
+    for (float s = max_ext; s > max_ext / 33.0f; s *= 0.96f) {
+        int d[3], cells = 1;
+        for (int a = 0; a < 3; ++a) {
+            d[a] = (int)std::fmin(32.0f, std::fmax(1.0f, std::ceil(ext[a] / s)));
+            cells *= d[a];
+        }
+        if (cells > budget) break;
+        for (int a = 0; a < 3; ++a) dim[a] = d[a];
+    }
+    rtgo::GridParams g = {};
+    float max_cs = 0.0f;
+    for (int a = 0; a < 3; ++a) max_cs = std::fmax(max_cs, ext[a] / (float)dim[a]);
+    const float pad = 2e-3f * max_cs + 1e-4f * reach_max;
+    for (int a = 0; a < 3; ++a) {
+        g.min[a] = lo[a] - 2.0f * pad;
+        g.n[a] = dim[a];
+        g.cs[a] = (ext[a] + 4.0f * pad) / (float)dim[a];
+        g.ics[a] = 1.0f / g.cs[a];
+    }
+    g.n_cells = dim[0] * dim[1] * dim[2];
+    g.margin = 0.5f * pad;
+    std::vector<std::vector<uint16_t>> lists((size_t)g.n_cells);
+    size_t total = 0;
+    for (int pos = 0; pos < ns; ++pos) {
+        int a0[3], a1[3];
+        for (int a = 0; a < 3; ++a) {
+            a0[a] = (int)std::floor((box[pos][a] - pad - g.min[a]) * g.ics[a]);
+            a1[a] = (int)std::floor((box[pos][3 + a] + pad - g.min[a]) * g.ics[a]);
+            a0[a] = a0[a] < 0 ? 0 : a0[a];
+            a1[a] = a1[a] > dim[a] - 1 ? dim[a] - 1 : a1[a];
+        }
+        for (int z = a0[2]; z <= a1[2]; ++z)
+            for (int y = a0[1]; y <= a1[1]; ++y)
+                for (int x = a0[0]; x <= a1[0]; ++x) {
+                    lists[((size_t)z * dim[1] + y) * dim[0] + x].push_back((uint16_t)pos);
+                    ++total;
+                }
+    }
+    if (total > 8 * (size_t)ns || total > 60000) return RTGO_OK;
+    const size_t bytes = ((size_t)g.n_cells * 4 + total * 2 + 31) / 32 * 32;
+    if (bytes > 28 * 1024) return RTGO_OK;
+    std::vector<unsigned char> img(bytes, 0);
+    uint32_t* cells = reinterpret_cast<uint32_t*>(img.data());
+    uint16_t* items = reinterpret_cast<uint16_t*>(img.data() + (size_t)g.n_cells * 4);
+    size_t at = 0;
+    for (int k = 0; k < g.n_cells; ++k) {
+        const std::vector<uint16_t>& l = lists[(size_t)k];
+        cells[k] = l.empty() ? 0u : (uint32_t)at | ((uint32_t)l.size() << 16);
+        for (uint16_t v : l) items[at++] = v;
+    }
+    RTGO_HIP(c, hipMalloc(&c->grid.d, bytes));
+    RTGO_HIP(c, hipMemcpyAsync(c->grid.d, img.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    RTGO_HIP(c, hipStreamSynchronize(c->stream));
+    c->grid.n_nodes = (int)(bytes / 32);
+    c->grid.gp = g;
+    c->grid.reach_max = reach_max;
+    c->grid.have = true;
+    if (std::getenv("RTGO_DEBUG"))
+        std::fprintf(stderr, "rtgo_set_scene: grid %d x %d x %d over %d primitives, %zu list entries, %zu bytes, pad %g, for rays within %g\n", dim[0], dim[1], dim[2], ns,
+                     total, bytes, pad, reach_max);
+    return RTGO_OK;
+}
+
 int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, uint32_t n)
 {
     if (!c || !prims) return fail(c, RTGO_E_INVALID, "rtgo_set_scene: NULL argument");
@@ -511,6 +626,8 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
     (void)hipFree(c->alt.d_fprims);
     c->alt = rtgo_ctx::FastTree();
     c->have_alt = false;
+    (void)hipFree(c->grid.d);
+    c->grid = rtgo_ctx::Grid();
     (void)hipFree(c->d_frames);
     (void)hipFree(c->d_tight);
     c->d_frames = nullptr;
@@ -587,6 +704,7 @@ int rtgo_set_scene(rtgo_ctx* c, const rtgo_prim* prims, const rtgo_aabb* aabbs, 
         // (the same split of primitives = the same structure: nothing to try)
         c->have_alt = sane && !(a.n_small == c->n_small && a.n_fnodes == c->n_fnodes && a.n_big_pairs == c->n_big_pairs && a.list_cub == c->list_cub);
     }
+    if (const int rc = build_grid(c, n)) return rc;
     if (std::getenv("RTGO_DEBUG"))
         std::fprintf(stderr, "rtgo_set_scene: %d primitives, %d in the fast walk's tree (%d nodes, depth %d), %d up front (%d pairs, cuboid certificate %d), %d cuboid leaves, margin coefficients %g %g, canonical LBVH depth %d\n",
                      (int)n, c->n_small, c->n_fnodes, c->fast_depth, (int)n - c->n_small, c->n_big_pairs, c->list_cub, meta[13], c->cub_a, c->cub_b, depth);
@@ -777,24 +895,41 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // (render_kernel, STREAM) lets a lane start its next sample when its path has ended instead of waiting for the wave's longest path,
     // pass after pass; and where rtgo_set_scene's two builds differ, either structure can be the faster one.  Candidate k = loop (k & 1:
     // 0 = streaming when there is a choice) | structure (k >> 1 when both loops are candidates, else k).
-    bool stream = false, use_alt = false;
+    bool stream = false;
+    int structure = 0;   // 0 / 1: the trees of 36 % / 15 %, 2: the grid
     unsigned char trial_tag = 0;
     if (!canon) {
         const bool multi_pass = passes_of(nn) > 1;
         const char* force_loop = std::getenv("RTGO_STREAM");   // "0" / "1": experiment and test knobs, no trial over that dimension
-        const char* force_tree = std::getenv("RTGO_TREE");     // "0" / "1": the 36 % / the 15 % structure
-        const bool loops = multi_pass && !force_loop, trees = c->have_alt && !force_tree;
+        const char* force_tree = std::getenv("RTGO_TREE");     // "0" / "1" / "2": the 36 % tree / the 15 % tree / the grid (when the scene has it)
+        // (the grid: where rtgo_set_scene built one, for rays that start within the reach its pad was sized for, and in the instantiations
+        // that exist -- not the flat-primitives one)
+        const bool flat_only = path && c->quadrics.empty() && !std::getenv("RTGO_NO_FRAMES");
+        const bool grid_ok = c->grid.have && c->guard_reach <= c->grid.reach_max && !flat_only;
+        int structs[3], n_structs = 0;
+        structs[n_structs++] = 0;
+        if (c->have_alt) structs[n_structs++] = 1;
+        if (grid_ok) structs[n_structs++] = 2;
+        if (force_tree) {
+            const int want = force_tree[0] - '0';
+            structure = 0;
+            for (int k = 0; k < n_structs; ++k)
+                if (structs[k] == want) structure = want;
+            n_structs = 1;
+            structs[0] = structure;
+        }
+        const bool loops = multi_pass && !force_loop;
         if (multi_pass && force_loop) stream = force_loop[0] != '0';
-        if (c->have_alt && force_tree) use_alt = force_tree[0] == '1';
-        const int n_cand = (loops ? 2 : 1) * (trees ? 2 : 1);
+        const int n_loops = loops ? 2 : 1;
+        const int n_cand = n_loops * n_structs;
         auto decode = [&](int k) {
-            if (loops) stream = (k & 1) == 0;
-            if (trees) use_alt = ((loops ? k >> 1 : k) & 1) != 0;
+            if (loops) stream = (k % n_loops) == 0;
+            structure = structs[k / n_loops];
         };
         if (n_cand > 1) {
             rtgo_ctx::Trial& t = c->trial;
             const std::vector<uint32_t> key = {p.W, p.H, p.x0, p.y0, p.w, p.h, p.band_h, p.n_ranks, p.rank, nn, (uint32_t)path, (uint32_t)f->max_trace_depth,
-                                               (uint32_t)(f->use_ambient != 0), (uint32_t)n_cand, (uint32_t)stream, (uint32_t)use_alt};
+                                               (uint32_t)(f->use_ambient != 0), (uint32_t)n_cand, (uint32_t)stream, (uint32_t)structure, (uint32_t)grid_ok};
             if (key != t.key) {
                 // (event tags of an unfinished trial of the old key stay where they are: they are counted into the old minima nobody reads)
                 t = rtgo_ctx::Trial();
@@ -822,9 +957,17 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
                 decode(k);
                 trial_tag = (unsigned char)(k + 1);
                 t.issued++;
-            } else decode(0);   // results pending
-        }
+            } else decode(0);   // (the trial's events were lost to a key change: start over with the first candidate)
+        } else if (n_structs == 1) structure = structs[0];
     }
+#ifdef RTGO_CMPWALK
+    if (canon)   // (diagnostic build: the instrumented launch also runs the pinned fast structure on every ray, rtgo_ray_trace.inc)
+        if (const char* want = std::getenv("RTGO_TREE")) {
+            if (want[0] == '1' && c->have_alt) structure = 1;
+            if (want[0] == '2' && c->grid.have && c->guard_reach <= c->grid.reach_max) structure = 2;
+        }
+#endif
+    const bool use_alt = structure == 1, use_grid = structure == 2;
     // the structure this launch walks
     const rtgo_ctx::FastTree ft = use_alt ? c->alt : [&] {
         rtgo_ctx::FastTree m;
@@ -972,13 +1115,15 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     }
     p.nodes = c->d_nodes;
     p.prims = c->d_prims;
-    p.fnodes = ft.d_fnodes;
-    p.n_fnodes = ft.n_fnodes;
+    p.fnodes = use_grid ? (const float4*)c->grid.d : ft.d_fnodes;
+    p.n_fnodes = use_grid ? c->grid.n_nodes : ft.n_fnodes;
+    p.grid = rtgo::GridParams();
+    if (use_grid) p.grid = c->grid.gp;
     p.fprims = ft.d_fprims;
     p.frames = c->d_frames;
     p.n_small = ft.n_small;
     p.n_big_pairs = ft.n_big_pairs;
-    p.stack_depth = canon ? kStackDepth : (ft.fast_depth > 0 ? ft.fast_depth : 1) + 1;   // (+1: fast_tree writes the slot past the top before it knows whether it pushes)
+    p.stack_depth = canon ? kStackDepth : ((ft.fast_depth > 0 && !use_grid) ? ft.fast_depth : 1) + 1;   // (+1: fast_tree writes the slot past the top before it knows whether it pushes)
     p.lights = c->d_lights;
     p.accum = c->d_accum;
     p.image = c->d_image;
@@ -1063,7 +1208,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     c->ev_tag[slot] = trial_tag;
     RTGO_HIP(c, hipEventRecord(c->ev_start[slot], c->stream));
     const float4* fp = (const float4*)ft.d_fprims;
-    const RenderKernel kernel = find_kernel(path, canon, wpe, stream, stats, frames);
+    const RenderKernel kernel = find_kernel(path, canon, wpe, stream, stats, frames, use_grid);
     if (!kernel) return fail(c, RTGO_E_UNSUPPORTED, "rtgo_launch: no kernel variant for this configuration");
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, c->stream, p, fp);
     RTGO_HIP(c, hipGetLastError());
@@ -1075,7 +1220,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     c->launches++;
     if (canon) c->launches_canonical++;
     if (trial_tag) c->launches_trial++;
-    c->last_variant = (stream ? 1u : 0u) | (use_alt ? 2u : 0u) | (canon ? 4u : 0u) | (trial_tag ? 8u : 0u);
+    c->last_variant = (stream ? 1u : 0u) | (use_alt ? 2u : 0u) | (canon ? 4u : 0u) | (trial_tag ? 8u : 0u) | (use_grid ? 16u : 0u);
     return RTGO_OK;
 }
 

@@ -40,6 +40,16 @@ struct LightRec {
     float corner[3], v1[3], v2[3], normal[3], color[3], falloff;  // device::SurfaceLight, params.h:73-87
 };
 
+// The fast walk's third structure (GRID instantiations): a uniform grid over the small primitives, walked cell by cell (fast_grid).
+// It travels in the buffer and the LDS region of the tree it replaces: n_cells words (first item | count << 16), then the items (16-bit
+// positions into fprims).
+struct GridParams {
+    float min[3], cs[3], ics[3];    // lower corner, cell size, 1 / cell size
+    int n[3];                       // cells per axis (<= 32 each)
+    int n_cells;
+    float margin;                   // fast_grid stops once the closest hit lies this far (in t) before the exit of the cell it is in
+};
+
 struct LaunchParams {
     const float4* nodes;            // canonical LBVH, 2 float4 per node
     const float4* prims;            // 6 float4 per primitive, SBT order
@@ -53,6 +63,7 @@ struct LaunchParams {
     int list_cub;                   // 1 / 2: the up-front list starts with three pairs certified as one box / one room (cuboid_range), 0: it does not
     float cub_mu;                   // cuboid_range's margin for this launch (object-space units of a face's y axis)
     int tree_spheres;               // 1: every primitive of the fast walk's tree is a sphere (balls): leaves go straight to the sphere test
+    GridParams grid;                // GRID instantiations: fnodes holds the grid instead of a tree
     const LightRec* lights;
     float4* accum;
     uchar4* image;
@@ -821,6 +832,81 @@ __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, c
     }
 }
 
+// fast_grid: the same job as fast_tree over a uniform grid (Amanatides & Woo's walk, one lane = one ray).  The host bins every small
+// primitive into the cells its box -- grown by a pad that is far above the rounding of the walk -- overlaps; a lane steps from cell to
+// cell along its ray, tests what the cell lists through the same leaf tests as the tree (so an accepted hit is the tree's and the
+// canonical walk's, bit for bit; a primitive met again in the next cell changes nothing: closer() is strict), and stops once its closest
+// hit lies before the exit of the cell it is in (everything that could beat it is listed in a cell already visited).  No stack, no box
+// tests: ~20 vector instructions per cell where the tree pays ~50 per node pair; scenes of many small, evenly spread primitives (balls).
+__device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, const float4* __restrict__ s_fprims, const GridParams& g, bool spheres,
+                                          v3 o, v3 d, float tmin, FastHit& best, unsigned int& dbg_boxes, unsigned int& dbg_tests)
+{
+    const unsigned int* __restrict__ cells = reinterpret_cast<const unsigned int*>(s_grid);
+    const unsigned short* __restrict__ items = reinterpret_cast<const unsigned short*>(cells + g.n_cells);
+    auto safe_rcp = [](float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(x), -1e30f, 1e30f); };   // (see fast_tree)
+    const v3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    // the ray's stretch inside the grid's bounds
+    float t0 = tmin, t1 = best.t;
+    {
+        const float ax = (g.min[0] - o.x) * id.x, bx = (g.min[0] + g.cs[0] * (float)g.n[0] - o.x) * id.x;
+        const float ay = (g.min[1] - o.y) * id.y, by = (g.min[1] + g.cs[1] * (float)g.n[1] - o.y) * id.y;
+        const float az = (g.min[2] - o.z) * id.z, bz = (g.min[2] + g.cs[2] * (float)g.n[2] - o.z) * id.z;
+        t0 = fmaxf(fmaxf(t0, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
+        t1 = fminf(fminf(t1, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
+    }
+    bool live = (g.n_cells > 0) & (t0 <= t1 * 1.000002f + g.margin);
+    // the cell of the entry point (clamped: the point may sit a rounding outside), the parameter at which the ray leaves it on each
+    // axis, the parameter per cell, and how many steps each axis has left
+    const float px = o.x + d.x * t0, py = o.y + d.y * t0, pz = o.z + d.z * t0;
+    int cx = min(max((int)floorf((px - g.min[0]) * g.ics[0]), 0), g.n[0] - 1);
+    int cy = min(max((int)floorf((py - g.min[1]) * g.ics[1]), 0), g.n[1] - 1);
+    int cz = min(max((int)floorf((pz - g.min[2]) * g.ics[2]), 0), g.n[2] - 1);
+    const bool fx = id.x >= 0.0f, fy = id.y >= 0.0f, fz = id.z >= 0.0f;
+    float tmx = (g.min[0] + g.cs[0] * (float)(cx + (fx ? 1 : 0)) - o.x) * id.x;
+    float tmy = (g.min[1] + g.cs[1] * (float)(cy + (fy ? 1 : 0)) - o.y) * id.y;
+    float tmz = (g.min[2] + g.cs[2] * (float)(cz + (fz ? 1 : 0)) - o.z) * id.z;
+    const float tdx = g.cs[0] * fabsf(id.x), tdy = g.cs[1] * fabsf(id.y), tdz = g.cs[2] * fabsf(id.z);
+    int rx = fx ? g.n[0] - 1 - cx : cx, ry = fy ? g.n[1] - 1 - cy : cy, rz = fz ? g.n[2] - 1 - cz : cz;
+    const int sx = fx ? 1 : -1, sy = fy ? g.n[0] : -g.n[0], sz = fz ? g.n[0] * g.n[1] : -(g.n[0] * g.n[1]);
+    int cell = (cz * g.n[1] + cy) * g.n[0] + cx;
+    // one step: out of the current cell through the nearest of its three far planes -- unless the closest hit so far lies before it
+    auto step = [&]() {
+        const bool ux = (tmx <= tmy) & (tmx <= tmz), uy = !ux & (tmy <= tmz);
+        const float te = ux ? tmx : (uy ? tmy : tmz);
+        rx -= ux ? 1 : 0;
+        ry -= uy ? 1 : 0;
+        rz -= (ux | uy) ? 0 : 1;
+        live = (best.t >= te - g.margin) & ((rx | ry | rz) >= 0);   // (a count below zero: that step left the grid)
+        tmx += ux ? tdx : 0.0f;
+        tmy += uy ? tdy : 0.0f;
+        tmz += (ux | uy) ? 0.0f : tdz;
+        cell += ux ? sx : (uy ? sy : sz);
+    };
+    while (live) {
+        unsigned int e = cells[cell];
+        while (live && e == 0u) {
+#ifdef RTGO_FAST_COUNTERS
+            dbg_boxes += 1;
+#endif
+            step();
+            if (live) e = cells[cell];
+        }
+        if (live) {
+            const int first = (int)(e & 0xFFFFu), cnt = (int)(e >> 16);
+#ifdef RTGO_FAST_COUNTERS
+            dbg_boxes += 1;
+            dbg_tests += (unsigned int)cnt;
+#endif
+            for (int k = 0; k < cnt; ++k) {
+                const int pos = (int)items[first + k];
+                if (spheres) sphere_leaf(s_fprims, pos, 1, o, d, tmin, best);
+                else leaf_test(s_fprims, pos, o, d, tmin, best);
+            }
+            step();
+        }
+    }
+}
+
 // fast_winner: the closest hit's record for the closest-hit program (t, SBT index, world normal)
 __device__ __forceinline__ bool fast_winner(const float4* __restrict__ s_fprims, v3 o, v3 d, float tmax, const FastHit& best, Hit& out)
 {
@@ -847,8 +933,9 @@ __device__ __forceinline__ bool fast_winner(const float4* __restrict__ s_fprims,
     return true;
 }
 
+template <bool GRID>
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 const float4* __restrict__ g_fprims,
+                                                 const float4* __restrict__ g_fprims, const GridParams& grid,
  unsigned int* __restrict__ s_stack, int bshift,
                                                  int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, bool tree_spheres, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests
@@ -872,7 +959,8 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     const unsigned long long tl_s1 = wall_clock64() + (best.pos == 12345 ? 1 : 0);
     tl_big += tl_s1 - tl_s0;
 #endif
-    fast_tree(s_fnodes, s_fprims, s_stack, bshift, n_small, cub_mu, o, d, tmin, best, dbg_boxes, dbg_tests, tree_spheres);
+    if constexpr (GRID) fast_grid(s_fnodes, s_fprims, grid, tree_spheres, o, d, tmin, best, dbg_boxes, dbg_tests);
+    else fast_tree(s_fnodes, s_fprims, s_stack, bshift, n_small, cub_mu, o, d, tmin, best, dbg_boxes, dbg_tests, tree_spheres);
 #ifdef RTGO_TIMELINE
     tl_tree += wall_clock64() + (best.pos == 12345 ? 1 : 0) - tl_s1;
 #endif
@@ -1041,7 +1129,7 @@ constexpr int kStreamWindow = 4;   // STREAM: passes a lane may run ahead of the
 // far-field guard, where it is the product path.
 // FRAMES: the scene holds flat primitives only (cornell, checkered): closest-hit takes N and the sampling tangent from the frames
 // build_kernel computed (bit for bit the per-hit values); an instantiation of its own, so that the other scenes' code is untouched.
-template <bool PATH, bool STATS, int WPE, bool STREAM, bool COUNT = STATS, bool FRAMES = false>
+template <bool PATH, bool STATS, int WPE, bool STREAM, bool COUNT = STATS, bool FRAMES = false, bool GRID = false>
 __global__ __launch_bounds__(kMaxBlock) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void render_kernel(const LaunchParams p, const float4* __restrict__ g_fprims)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
