@@ -494,13 +494,13 @@ int rtgo_set_stream(rtgo_ctx* c, void* hip_stream)
 // The uniform grid of rtgo::fast_grid over structure 0's small primitives (fprims [0, n_small)), from the boxes the fast walk culls
 // with (c->tight: build_kernel's, SBT order).  Every box is grown by `pad` before it is binned, and fast_grid stops `pad / 2` (in t)
 // late: the walk's own rounding (entry point, 96 accumulated steps: <= ~2e-5 of the rays' reach) stays an order of magnitude inside.
-// Cells: ~ lambda per primitive (RTGO_GRID_LAMBDA, default 4), <= 32 per axis, <= 4096; no grid for fewer than 24 small primitives
-// or when the lists come out longer than 8 entries per primitive (a few big shapes among small ones: the tree's job).
+// Cells: <= 32 per axis, table and lists within 32 KB of LDS; no grid for fewer than 64 small primitives (RTGO_GRID_MIN) or when every
+// resolution lists more than 3 entries per primitive (RTGO_GRID_MAX_DUP; a few big shapes among small ones: the tree's job).
 static int build_grid(rtgo_ctx* c, uint32_t n)
 {
     c->grid.have = false;
     const int ns = c->n_small;
-    if (ns < 24 || std::getenv("RTGO_NO_GRID")) return RTGO_OK;
+    if (ns < (int)env_uint("RTGO_GRID_MIN", 64) || std::getenv("RTGO_NO_GRID")) return RTGO_OK;
     std::vector<float4> fp((size_t)n * 4);
     RTGO_HIP(c, hipMemcpyAsync(fp.data(), c->d_fprims, fp.size() * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
@@ -524,51 +524,92 @@ static int build_grid(rtgo_ctx* c, uint32_t n)
         max_ext = std::fmax(max_ext, ext[a]);
     }
     if (!(max_ext > 0.0f)) return RTGO_OK;
-    // the finest cubic cell whose grid stays within the budget
-    const float lambda = env_float("RTGO_GRID_LAMBDA", 4.0f);
-    const int budget = (int)std::fmin(4096.0f, std::fmax(8.0f, lambda * (float)ns));
-    int dim[3] = {1, 1, 1};
-    for (float s = max_ext; s > max_ext / 33.0f; s *= 0.96f) {
-        int d[3], cells = 1;
-        for (int a = 0; a < 3; ++a) {
-            d[a] = (int)std::fmin(32.0f, std::fmax(1.0f, std::ceil(ext[a] / s)));
-            cells *= d[a];
+    // Resolution: the (nx, ny, nz) that minimises the classic cost of a grid walk -- a ray meets cells in proportion to their surface
+    // area, pays one step per cell and one test per list entry: cost = A_cell (n_cells + kTest entries) -- over every resolution
+    // up to 32 per axis, with the entries counted exactly (a primitive's span of cells is separable per axis).  The entries term is what
+    // matters: a resolution that cuts through the shapes lists them two to eight times (balls, profiles/r03r: 16 x 4 x 16, one sphere per
+    // column, 321 entries, 10.1 ms; 13 x 6 x 13, 754 entries, 13.8 ms; 32 x 1 x 32, 1024 entries, 19.1 ms; the tree 13.5).  kTest fitted there.
+    const float kTest = env_float("RTGO_GRID_KTEST", 1.7f), max_dup = env_float("RTGO_GRID_MAX_DUP", 3.0f);
+    const float pad0 = 2e-3f * (max_ext / 8.0f) + 1e-4f * reach_max;   // (the pad of the binning below depends on the cell size: close enough for counting)
+    std::vector<uint8_t> span[3];
+    for (int a = 0; a < 3; ++a) {
+        span[a].assign((size_t)33 * ns, 1);
+        for (int m = 1; m <= 32; ++m) {
+            const float g0 = lo[a] - 2.0f * pad0, ics = (float)m / (ext[a] + 4.0f * pad0);
+            for (int pos = 0; pos < ns; ++pos) {
+                int c0 = (int)std::floor((box[pos][a] - pad0 - g0) * ics), c1 = (int)std::floor((box[pos][3 + a] + pad0 - g0) * ics);
+                c0 = c0 < 0 ? 0 : c0;
+                c1 = c1 > m - 1 ? m - 1 : c1;
+                span[a][(size_t)m * ns + pos] = (uint8_t)(c1 - c0 + 1);
+            }
         }
-        if (cells > budget) break;
-        for (int a = 0; a < 3; ++a) dim[a] = d[a];
+    }
+    int dim[3] = {1, 1, 1};
+    double best_cost = 1e300;
+    std::vector<uint32_t> sxy((size_t)ns);
+    for (int mx = 1; mx <= 32; ++mx)
+        for (int my = 1; my <= 32; ++my) {
+            if ((mx + 2) * (my + 2) * 3 * 4 > 32 * 1024) continue;
+            for (int pos = 0; pos < ns; ++pos) sxy[pos] = (uint32_t)span[0][(size_t)mx * ns + pos] * span[1][(size_t)my * ns + pos];
+            for (int mz = 1; mz <= 32; ++mz) {
+                const size_t words = (size_t)(mx + 2) * (my + 2) * (mz + 2);
+                if (words * 4 > 30 * 1024) break;
+                size_t entries = 0;
+                const uint8_t* sz = &span[2][(size_t)mz * ns];
+                for (int pos = 0; pos < ns; ++pos) entries += (size_t)sxy[pos] * sz[pos];
+                if ((float)entries > max_dup * (float)ns || words * 4 + entries * 2 > 32 * 1024) continue;
+                const double cx = (ext[0] + 4.0 * pad0) / mx, cy = (ext[1] + 4.0 * pad0) / my, cz = (ext[2] + 4.0 * pad0) / mz;
+                const double cost = 2.0 * (cx * cy + cy * cz + cx * cz) * ((double)mx * my * mz + (double)kTest * (double)entries);
+                if (cost < best_cost) {
+                    best_cost = cost;
+                    dim[0] = mx; dim[1] = my; dim[2] = mz;
+                }
+            }
+        }
+    if (best_cost >= 1e300) return RTGO_OK;
+    if (const char* want = std::getenv("RTGO_GRID_DIMS")) {   // "nx,ny,nz": experiments
+        int d[3];
+        if (std::sscanf(want, "%d,%d,%d", &d[0], &d[1], &d[2]) == 3)
+            for (int a = 0; a < 3; ++a) dim[a] = d[a] < 1 ? 1 : (d[a] > 32 ? 32 : d[a]);
     }
     rtgo::GridParams g = {};
     float max_cs = 0.0f;
     for (int a = 0; a < 3; ++a) max_cs = std::fmax(max_cs, ext[a] / (float)dim[a]);
     const float pad = 2e-3f * max_cs + 1e-4f * reach_max;
+    float gmin[3], gcs[3], gics[3];
     for (int a = 0; a < 3; ++a) {
-        g.min[a] = lo[a] - 2.0f * pad;
-        g.n[a] = dim[a];
-        g.cs[a] = (ext[a] + 4.0f * pad) / (float)dim[a];
-        g.ics[a] = 1.0f / g.cs[a];
+        gmin[a] = lo[a] - 2.0f * pad;
+        gcs[a] = (ext[a] + 4.0f * pad) / (float)dim[a];
+        gics[a] = 1.0f / gcs[a];
     }
-    g.n_cells = dim[0] * dim[1] * dim[2];
+    g.min_x = gmin[0]; g.min_y = gmin[1]; g.min_z = gmin[2];
+    g.cs_x = gcs[0]; g.cs_y = gcs[1]; g.cs_z = gcs[2];
+    g.ics_x = gics[0]; g.ics_y = gics[1]; g.ics_z = gics[2];
+    g.nx = dim[0]; g.ny = dim[1]; g.nz = dim[2];
+    // the table carries a border of empty cells (fast_grid steps into it when it leaves the grid)
+    const int NX = dim[0] + 2, NY = dim[1] + 2, NZ = dim[2] + 2;
+    g.n_cells = NX * NY * NZ;
     g.margin = 0.5f * pad;
     std::vector<std::vector<uint16_t>> lists((size_t)g.n_cells);
     size_t total = 0;
     for (int pos = 0; pos < ns; ++pos) {
         int a0[3], a1[3];
         for (int a = 0; a < 3; ++a) {
-            a0[a] = (int)std::floor((box[pos][a] - pad - g.min[a]) * g.ics[a]);
-            a1[a] = (int)std::floor((box[pos][3 + a] + pad - g.min[a]) * g.ics[a]);
+            a0[a] = (int)std::floor((box[pos][a] - pad - gmin[a]) * gics[a]);
+            a1[a] = (int)std::floor((box[pos][3 + a] + pad - gmin[a]) * gics[a]);
             a0[a] = a0[a] < 0 ? 0 : a0[a];
             a1[a] = a1[a] > dim[a] - 1 ? dim[a] - 1 : a1[a];
         }
         for (int z = a0[2]; z <= a1[2]; ++z)
             for (int y = a0[1]; y <= a1[1]; ++y)
                 for (int x = a0[0]; x <= a1[0]; ++x) {
-                    lists[((size_t)z * dim[1] + y) * dim[0] + x].push_back((uint16_t)pos);
+                    lists[((size_t)(z + 1) * NY + (y + 1)) * NX + (x + 1)].push_back((uint16_t)pos);
                     ++total;
                 }
     }
-    if (total > 8 * (size_t)ns || total > 60000) return RTGO_OK;
+    if ((float)total > (max_dup + 0.5f) * (float)ns || total > 60000) return RTGO_OK;   // (the binning's pad is a little larger than the count's)
     const size_t bytes = ((size_t)g.n_cells * 4 + total * 2 + 31) / 32 * 32;
-    if (bytes > 28 * 1024) return RTGO_OK;
+    if (bytes > 32 * 1024) return RTGO_OK;
     std::vector<unsigned char> img(bytes, 0);
     uint32_t* cells = reinterpret_cast<uint32_t*>(img.data());
     uint16_t* items = reinterpret_cast<uint16_t*>(img.data() + (size_t)g.n_cells * 4);
@@ -1155,7 +1196,7 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     // LDS image of the chosen kernel (see render_kernel): canonical = nodes + 6/prim; fast = fnodes + 4/prim + 3/prim.
     // The scene copy is per workgroup and the stack per lane, so bigger scenes want bigger workgroups: pick the size that
     // puts the most waves on a CU (at most 16 = 4 per SIMD, what the kernel's VGPR budget admits), smallest size on ties.
-    const int fast_nodes = ft.n_fnodes;
+    const int fast_nodes = p.n_fnodes;   // (the tree's nodes, or the grid in their place)
     frames = path && !canon && c->quadrics.empty() && !std::getenv("RTGO_NO_FRAMES");   // scenes of flat primitives only: N and the sampling tangent from LDS
     const size_t scene_lds = (size_t)(2 * (canon ? p.n_nodes : fast_nodes) + (canon ? 6 : 7) * p.n_prims + (frames ? 2 * p.n_prims : 0) /* shading frames */) * sizeof(float4) +
                              (size_t)kMaxLights * sizeof(LightRec) + 16 * sizeof(float) +   // + the raygen constants

@@ -44,9 +44,9 @@ struct LightRec {
 // It travels in the buffer and the LDS region of the tree it replaces: n_cells words (first item | count << 16), then the items (16-bit
 // positions into fprims).
 struct GridParams {
-    float min[3], cs[3], ics[3];    // lower corner, cell size, 1 / cell size
-    int n[3];                       // cells per axis (<= 32 each)
-    int n_cells;
+    float min_x, min_y, min_z, cs_x, cs_y, cs_z, ics_x, ics_y, ics_z;   // lower corner, cell size, 1 / cell size
+    int nx, ny, nz;                 // cells per axis (<= 32 each)
+    int n_cells;                    // words of the table: (nx + 2) (ny + 2) (nz + 2), a border of empty cells around the grid
     float margin;                   // fast_grid stops once the closest hit lies this far (in t) before the exit of the cell it is in
 };
 
@@ -838,71 +838,75 @@ __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, c
 // canonical walk's, bit for bit; a primitive met again in the next cell changes nothing: closer() is strict), and stops once its closest
 // hit lies before the exit of the cell it is in (everything that could beat it is listed in a cell already visited).  No stack, no box
 // tests: ~20 vector instructions per cell where the tree pays ~50 per node pair; scenes of many small, evenly spread primitives (balls).
-__device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, const float4* __restrict__ s_fprims, const GridParams& g, bool spheres,
+__device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, const float4* __restrict__ s_fprims, const GridParams g, bool spheres,
                                           v3 o, v3 d, float tmin, FastHit& best, unsigned int& dbg_boxes, unsigned int& dbg_tests)
 {
+    // (everything of `g` into scalars first: it is wave-uniform, and a struct member read inside the loop through a reference went to scratch)
+    const float gx = g.min_x, gy = g.min_y, gz = g.min_z, csx = g.cs_x, csy = g.cs_y, csz = g.cs_z, margin = g.margin;
+    const int nx = g.nx, ny = g.ny, nz = g.nz, n_cells = g.n_cells;
     const unsigned int* __restrict__ cells = reinterpret_cast<const unsigned int*>(s_grid);
-    const unsigned short* __restrict__ items = reinterpret_cast<const unsigned short*>(cells + g.n_cells);
-    auto safe_rcp = [](float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(x), -1e30f, 1e30f); };   // (see fast_tree)
-    const v3 id = mk(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const unsigned short* __restrict__ items = reinterpret_cast<const unsigned short*>(cells + n_cells);
+    const float idx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e30f, 1e30f);   // (see fast_tree on 1 / 0)
+    const float idy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e30f, 1e30f);
+    const float idz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e30f, 1e30f);
     // the ray's stretch inside the grid's bounds
     float t0 = tmin, t1 = best.t;
     {
-        const float ax = (g.min[0] - o.x) * id.x, bx = (g.min[0] + g.cs[0] * (float)g.n[0] - o.x) * id.x;
-        const float ay = (g.min[1] - o.y) * id.y, by = (g.min[1] + g.cs[1] * (float)g.n[1] - o.y) * id.y;
-        const float az = (g.min[2] - o.z) * id.z, bz = (g.min[2] + g.cs[2] * (float)g.n[2] - o.z) * id.z;
+        const float ax = (gx - o.x) * idx, bx = (gx + csx * (float)nx - o.x) * idx;
+        const float ay = (gy - o.y) * idy, by = (gy + csy * (float)ny - o.y) * idy;
+        const float az = (gz - o.z) * idz, bz = (gz + csz * (float)nz - o.z) * idz;
         t0 = fmaxf(fmaxf(t0, fminf(ax, bx)), fmaxf(fminf(ay, by), fminf(az, bz)));
         t1 = fminf(fminf(t1, fmaxf(ax, bx)), fminf(fmaxf(ay, by), fmaxf(az, bz)));
     }
-    bool live = (g.n_cells > 0) & (t0 <= t1 * 1.000002f + g.margin);
+    bool live = (n_cells > 0) & (t0 <= t1 * 1.000002f + margin);
     // the cell of the entry point (clamped: the point may sit a rounding outside), the parameter at which the ray leaves it on each
-    // axis, the parameter per cell, and how many steps each axis has left
-    const float px = o.x + d.x * t0, py = o.y + d.y * t0, pz = o.z + d.z * t0;
-    int cx = min(max((int)floorf((px - g.min[0]) * g.ics[0]), 0), g.n[0] - 1);
-    int cy = min(max((int)floorf((py - g.min[1]) * g.ics[1]), 0), g.n[1] - 1);
-    int cz = min(max((int)floorf((pz - g.min[2]) * g.ics[2]), 0), g.n[2] - 1);
-    const bool fx = id.x >= 0.0f, fy = id.y >= 0.0f, fz = id.z >= 0.0f;
-    float tmx = (g.min[0] + g.cs[0] * (float)(cx + (fx ? 1 : 0)) - o.x) * id.x;
-    float tmy = (g.min[1] + g.cs[1] * (float)(cy + (fy ? 1 : 0)) - o.y) * id.y;
-    float tmz = (g.min[2] + g.cs[2] * (float)(cz + (fz ? 1 : 0)) - o.z) * id.z;
-    const float tdx = g.cs[0] * fabsf(id.x), tdy = g.cs[1] * fabsf(id.y), tdz = g.cs[2] * fabsf(id.z);
-    int rx = fx ? g.n[0] - 1 - cx : cx, ry = fy ? g.n[1] - 1 - cy : cy, rz = fz ? g.n[2] - 1 - cz : cz;
-    const int sx = fx ? 1 : -1, sy = fy ? g.n[0] : -g.n[0], sz = fz ? g.n[0] * g.n[1] : -(g.n[0] * g.n[1]);
-    int cell = (cz * g.n[1] + cy) * g.n[0] + cx;
-    // one step: out of the current cell through the nearest of its three far planes -- unless the closest hit so far lies before it
-    auto step = [&]() {
-        const bool ux = (tmx <= tmy) & (tmx <= tmz), uy = !ux & (tmy <= tmz);
-        const float te = ux ? tmx : (uy ? tmy : tmz);
-        rx -= ux ? 1 : 0;
-        ry -= uy ? 1 : 0;
-        rz -= (ux | uy) ? 0 : 1;
-        live = (best.t >= te - g.margin) & ((rx | ry | rz) >= 0);   // (a count below zero: that step left the grid)
-        tmx += ux ? tdx : 0.0f;
-        tmy += uy ? tdy : 0.0f;
-        tmz += (ux | uy) ? 0.0f : tdz;
-        cell += ux ? sx : (uy ? sy : sz);
-    };
+    // axis and the parameter per cell.  The table has a border of empty cells around the nx x ny x nz that list something: the step
+    // out of the grid lands there and the walk ends on the parameter test alone, without a count of cells per axis (a ray leaves through
+    // a face, an edge or a corner: at most one step per axis beyond t1, all inside the border).
+    const int cx = min(max((int)floorf((o.x + d.x * t0 - gx) * g.ics_x), 0), nx - 1);
+    const int cy = min(max((int)floorf((o.y + d.y * t0 - gy) * g.ics_y), 0), ny - 1);
+    const int cz = min(max((int)floorf((o.z + d.z * t0 - gz) * g.ics_z), 0), nz - 1);
+    const bool fx = idx >= 0.0f, fy = idy >= 0.0f, fz = idz >= 0.0f;
+    float tmx = (gx + csx * (float)(cx + (fx ? 1 : 0)) - o.x) * idx;
+    float tmy = (gy + csy * (float)(cy + (fy ? 1 : 0)) - o.y) * idy;
+    float tmz = (gz + csz * (float)(cz + (fz ? 1 : 0)) - o.z) * idz;
+    const float tdx = csx * fabsf(idx), tdy = csy * fabsf(idy), tdz = csz * fabsf(idz);
+    const int NX = nx + 2, NXY = NX * (ny + 2);
+    const int sx = fx ? 1 : -1, sy = fy ? NX : -NX, sz = fz ? NXY : -NXY;
+    int cell = (cz + 1) * NXY + (cy + 1) * NX + cx + 1;
+    float tstop = fminf(best.t, t1) + margin;   // the walk goes on while the current cell's exit lies before this
+    int last = -1;                              // the record tested last: a shape that straddles two cells along the ray is listed in both
+    unsigned int e = live ? cells[cell] : 0u;
     while (live) {
-        unsigned int e = cells[cell];
+        // to the next cell that lists something: out of the current one through the nearest of its three far planes
         while (live && e == 0u) {
 #ifdef RTGO_FAST_COUNTERS
             dbg_boxes += 1;
 #endif
-            step();
+            const bool ux = (tmx <= tmy) & (tmx <= tmz), uy = !ux & (tmy <= tmz);
+            const float te = ux ? tmx : (uy ? tmy : tmz);
+            live = te <= tstop;
+            tmx += ux ? tdx : 0.0f;
+            tmy += uy ? tdy : 0.0f;
+            tmz += (ux | uy) ? 0.0f : tdz;
+            cell += ux ? sx : (uy ? sy : sz);
             if (live) e = cells[cell];
         }
         if (live) {
             const int first = (int)(e & 0xFFFFu), cnt = (int)(e >> 16);
-#ifdef RTGO_FAST_COUNTERS
-            dbg_boxes += 1;
-            dbg_tests += (unsigned int)cnt;
-#endif
             for (int k = 0; k < cnt; ++k) {
                 const int pos = (int)items[first + k];
-                if (spheres) sphere_leaf(s_fprims, pos, 1, o, d, tmin, best);
-                else leaf_test(s_fprims, pos, o, d, tmin, best);
+                if (pos != last) {
+#ifdef RTGO_FAST_COUNTERS
+                    dbg_tests += 1;
+#endif
+                    if (spheres) sphere_leaf(s_fprims, pos, 1, o, d, tmin, best);
+                    else leaf_test(s_fprims, pos, o, d, tmin, best);
+                }
+                last = pos;
             }
-            step();
+            tstop = fminf(best.t, t1) + margin;
+            e = 0u;   // (back into the stepping loop)
         }
     }
 }
@@ -935,7 +939,7 @@ __device__ __forceinline__ bool fast_winner(const float4* __restrict__ s_fprims,
 
 template <bool GRID>
 __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fnodes, const float4* __restrict__ s_fprims,
-                                                 const float4* __restrict__ g_fprims, const GridParams& grid,
+                                                 const float4* __restrict__ g_fprims, const GridParams grid,
  unsigned int* __restrict__ s_stack, int bshift,
                                                  int n_small, int n_prims, int n_big_pairs, int list_cub, float cub_mu, bool tree_spheres, v3 o, v3 d, float tmin, float tmax, Hit& out,
                                                  unsigned int& dbg_boxes, unsigned int& dbg_tests

@@ -1319,16 +1319,86 @@ def test_the_two_fast_structures_and_the_trial_are_bitwise_the_same(capi, oracle
     sc, t, ctx = upload(capi, oracle, name, W, H)
     for n, path in ((2, True), (5, True), (3, False)):
         canon, cimg = gpu_render(capi, ctx, W, H, n, 1, path, stats=True, prev=np.full((H, W, 4), 0.5, np.float32))
-        for pin in ("0", "1", None):
+        for pin in ("0", "1", "2", None):          # ("2": the uniform grid, in the scenes that have one -- structure 0 otherwise)
             if pin is None:
                 monkeypatch.delenv("RTGO_TREE", raising=False)
             else:
                 monkeypatch.setenv("RTGO_TREE", pin)
-            for rep in range(12 if pin is None else 1):
+            for rep in range(16 if pin is None else 1):
                 acc, img = gpu_render(capi, ctx, W, H, n, 1, path, prev=np.full((H, W, 4), 0.5, np.float32))
                 assert np.array_equal(acc.view(np.uint32), canon.view(np.uint32)) and np.array_equal(img, cimg), (name, n, path, pin, rep)
+                if pin == "2" and name == "balls":
+                    assert ctx.stats()["last_variant"] & 16, "balls has a grid"
+
     monkeypatch.delenv("RTGO_TREE", raising=False)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["random", "boxes", "boxes_spheres"])
+def test_uniform_grid_walk_on_random_scenes(capi, oracle, kind, monkeypatch):
+    """rtgo::fast_grid (the fast walk's third structure: a uniform grid over the small primitives, built by rtgo_set_scene, DESIGN.md 3.1) on the
+    tests' random scenes -- all four primitive types under random non-uniform transforms / rooms full of boxes of six rectangles, with spheres
+    between them -- with the grid forced onto scenes it would not normally be built for (RTGO_GRID_MIN, RTGO_GRID_MAX_DUP) and pinned
+    (RTGO_TREE=2): the frame is the canonical walk's bit for bit, from inside and from 30 scene sizes away, and beyond the reach its pad was
+    sized for the launch walks the tree instead.  tools/fuzz_scenes.py / fuzz_farfield.py / cmp_walks.py with the same pins compare ray by ray
+    (profiles/r03s)."""
+    monkeypatch.setenv("RTGO_GRID_MIN", "4")
+    monkeypatch.setenv("RTGO_GRID_MAX_DUP", "8")
+    W, H = 96, 64
+    on_grid = 0
+    for seed in range(8):
+        if kind == "random":
+            sc, t = _random_scene(oracle, 40 + seed, W, H)
+        else:
+            sc, t = _box_scene(oracle, 40 + seed, W, H, 3 + 4 * seed, kind == "boxes_spheres", bool(seed & 1))
+        ctx = capi.Context(0)
+        ctx.set_scene(t["type"], t["M"], t["mat"], t["aabb"] if seed & 2 else None)
+        ctx.set_background(t["bg"])
+        ctx.set_lights(t["lights"])
+        bb = np.asarray(t["aabb"], dtype=np.float64).reshape(-1, 6)
+        centre, size = 0.5 * (bb[:, :3].min(axis=0) + bb[:, 3:].max(axis=0)), float(np.abs(bb).max())
+        rng = np.random.default_rng(seed)
+        for dist, fov in ((0.2, 100.0), (1.5, 50.0), (30.0, 4.0)):
+            d = rng.normal(size=3)
+            eye = oracle.f32(centre + d / np.linalg.norm(d) * size * dist)
+            U, V, Wv = [np.zeros(3, dtype=np.float32) for _ in range(3)]
+            oracle.lib().oracle_camera_uvw(oracle.fptr(eye), oracle.fptr(oracle.f32(centre)), oracle.fptr(oracle.f32([0.1, 1, 0.05])), fov,
+                                           np.float32(np.float32(W) / np.float32(H)), oracle.fptr(U), oracle.fptr(V), oracle.fptr(Wv))
+            ctx.set_camera(eye, U, V, Wv)
+            for n, path in ((2, True), (3, False)):
+                monkeypatch.delenv("RTGO_TREE", raising=False)
+                canon, cimg = gpu_render(capi, ctx, W, H, n, 2, path, stats=True, prev=np.full((H, W, 4), 0.25, np.float32))
+                monkeypatch.setenv("RTGO_TREE", "2")
+                acc, img = gpu_render(capi, ctx, W, H, n, 2, path, prev=np.full((H, W, 4), 0.25, np.float32))
+                st = ctx.stats()
+                assert np.array_equal(acc.view(np.uint32), canon.view(np.uint32)) and np.array_equal(img, cimg), (kind, seed, dist, n, path, st)
+                if st["last_variant"] & 16:
+                    on_grid += 1
+                    assert dist < 4.0 and not (st["last_variant"] & 4), st      # (30 scene sizes away: beyond the grid's reach, the tree walks)
+        ctx.close()
+    monkeypatch.delenv("RTGO_TREE", raising=False)
+    assert on_grid >= 8, on_grid
+
+
+@pytest.mark.gpu
+def test_uniform_grid_walk_on_balls(capi, oracle, monkeypatch):
+    """balls (256 spheres in a room: the one reference scene whose grid the build keeps by default, 16 x 4 x 16 cells) at its own size and moved
+    300 units off the origin: grid == both trees == canonical, bit for bit, in every mode; an unpinned job settles on one candidate."""
+    W, H = 240, 136
+    for shift in ((0.0, 0.0, 0.0), (300.0, -120.0, 40.0)):
+        sc, ctx = _shifted_upload(capi, oracle, "balls", W, H, shift, (0.0, 0.0, 14.0))
+        for n, path, amb in ((4, True, False), (2, False, False), (5, False, True)):
+            monkeypatch.delenv("RTGO_TREE", raising=False)
+            canon, cimg = gpu_render(capi, ctx, W, H, n, 1, path, ambient=amb, stats=True, prev=np.full((H, W, 4), 0.5, np.float32))
+            for pin in ("2", "0", "1"):
+                monkeypatch.setenv("RTGO_TREE", pin)
+                acc, img = gpu_render(capi, ctx, W, H, n, 1, path, ambient=amb, prev=np.full((H, W, 4), 0.5, np.float32))
+                st = ctx.stats()
+                assert np.array_equal(acc.view(np.uint32), canon.view(np.uint32)) and np.array_equal(img, cimg), (shift, n, path, pin)
+                assert bool(st["last_variant"] & 16) == (pin == "2"), st
+        monkeypatch.delenv("RTGO_TREE", raising=False)
+        ctx.close()
 
 
 @pytest.mark.gpu

@@ -24,11 +24,12 @@ for name in ["cornell", "slide", "mirror_spheres", "plateau", "window", "checker
         for f in range(F):
             ctx.launch(capi.make_frame(W, H, N, f, mode == "path", mode == "ambient", stats=True))
         ctx.sync()
-        rays = ctx.stats()["rays_total"]
+        st = ctx.stats()
+        rays = st["rays_total"]
         lib.rtgo_debug_cmpwalk(ctx._h, buf.ctypes.data, buf.nbytes)
         bad = int(buf[0].view(np.uint32)[0])
         total_rays += rays; total_bad += bad
-        print("%-14s %-11s %12d rays, %d on which the walks disagree" % (name, mode, rays, bad), flush=True)
+        print("%-14s %-11s %12d rays, %d on which the walks disagree%s" % (name, mode, rays, bad, " (fast walk: the uniform grid)" if st["last_variant"] & 16 else ""), flush=True)
         for r in buf[1:1 + min(bad, 4)]:
             print("    o", r[0:3], "d", r[3:6], "tmin", r[6], "tmax", r[7], "canonical (t, prim)", r[8], int(r[9]), "fast", r[10], int(r[11]), "depth", int(r[12]), "phase", int(r[13]))
     ctx.close()

@@ -29,6 +29,7 @@ rays_by = np.zeros(len(EDGES) - 1, dtype=np.int64); bad_by = np.zeros(len(EDGES)
 flat_by = np.zeros(len(EDGES) - 1, dtype=np.int64)    # disagreements (first 255 per launch) between two flat primitives / a hit and a miss of one
 qrays_by = np.zeros(len(QEDGES) - 1, dtype=np.int64); qbad_by = np.zeros(len(QEDGES) - 1, dtype=np.int64); qlaunches_by = np.zeros(len(QEDGES) - 1, dtype=np.int64)
 px_bad = 0
+grid_cmp = 0; grid_product = 0
 worst = []
 rows = []
 
@@ -43,6 +44,8 @@ def shifted(t, s):
 
 
 for seed in range(first, first + count):
+    if (seed - first) % 10 == 0:
+        print("... seed %d, %d launches so far, %d rays, %d disagreements" % (seed, int(launches_by.sum()), int(rays_by.sum()), int(bad_by.sum())), flush=True)
     rng = np.random.default_rng(77000 + seed)
     kind = seed % 4
     if kind == 0:
@@ -81,6 +84,7 @@ for seed in range(first, first + count):
         ctx.launch(capi.make_frame(W, H, n, 0, path, amb, stats=True)); ctx.sync()
         canon = ctx.read_accum(H, W).copy()
         st = ctx.stats()
+        grid_cmp += 1 if st["last_variant"] & 16 else 0          # (RTGO_TREE=2: the walk compared with the canonical one was the grid's)
         rays, reach, quad = st["rays_total"], float(st["guard_reach"]), float(st["guard_quadric"])   # the guard's two quantities, as rtgo_launch computed them
         b = int(np.searchsorted(EDGES, reach, side="right") - 1); qb = int(np.searchsorted(QEDGES, quad, side="right") - 1)
         lib.rtgo_debug_cmpwalk(ctx._h, buf.ctypes.data, buf.nbytes)
@@ -102,7 +106,9 @@ for seed in range(first, first + count):
         ctx.reset_stats()
         ctx.launch(capi.make_frame(W, H, n, 0, path, amb, stats=False)); ctx.sync()
         fast = ctx.read_accum(H, W)
-        took_canonical = ctx.stats()["launches_canonical"]
+        pst = ctx.stats()
+        took_canonical = pst["launches_canonical"]
+        grid_product += 1 if pst["last_variant"] & 16 else 0
         if not np.array_equal(fast.view(np.uint32), canon.view(np.uint32)):
             px_bad += 1
             print("PIXEL MISMATCH %s seed %d trial %d reach %.1f quadric %.0f (product launch walked %s)" % (name, seed, trial, reach, quad, "canonical" if took_canonical else "fast"), flush=True)
@@ -116,6 +122,7 @@ for i in range(len(QEDGES) - 1):
     if qlaunches_by[i]:
         print("  quadric [%8g, %8g): %5d launches %14d rays %6d disagreements" % (QEDGES[i], QEDGES[i + 1], qlaunches_by[i], qrays_by[i], qbad_by[i]))
 print("product launches whose frame differs from the instrumented (canonical) frame: %d" % px_bad)
+print("launches that walked the uniform grid (RTGO_TREE=2): %d of the instrumented comparisons, %d of the product launches" % (grid_cmp, grid_product))
 print("launches with disagreements, by reach:")
 for (reach, quad, name, seed, trial, k, kflat, r) in sorted(worst, key=lambda w: w[0])[:16]:
     print("  reach %.1f quadric %.0f %s seed %d trial %d: %d rays (%d flat); first o %s d %s canonical (%g, %d) fast (%g, %d)" %

@@ -13,7 +13,7 @@ tg = importlib.util.module_from_spec(spec); spec.loader.exec_module(tg)
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 W, H = 96, 64
-bad = 0; launches = 0; ray_bad = 0
+bad = 0; launches = 0; ray_bad = 0; grid_launches = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     kind = seed % 3
@@ -47,6 +47,7 @@ for seed in range(first, first + count):
             ctx.write_accum(prev)
             ctx.launch(capi.make_frame(W, H, n, frame, path, amb, win, (4, G, g), max_depth=md, stats=stats)); ctx.sync()
             outs.append(ctx.read_accum(rows, w).copy())
+            grid_launches += 1 if ctx.stats()["last_variant"] & 16 else 0
         launches += 1
         if not np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32)):
             bad += 1
@@ -63,4 +64,4 @@ for seed in range(first, first + count):
             print("seed %d: %d rays on which the walks disagree; first: o %s d %s tmin %g tmax %g canonical (%g, %d) fast (%g, %d)" %
                   (seed, k, buf[1, 0:3], buf[1, 3:6], buf[1, 6], buf[1, 7], buf[1, 8], int(buf[1, 9]), buf[1, 10], int(buf[1, 11])))
     ctx.close()
-print("%d scenes, %d launch pairs, %d mismatches; rays on which the walks disagree (RTGO_CMPWALK build only): %d" % (count, launches, bad, ray_bad))
+print("%d scenes, %d launch pairs, %d mismatches; rays on which the walks disagree (RTGO_CMPWALK build only): %d; launches on the uniform grid (RTGO_TREE=2): %d of %d" % (count, launches, bad, ray_bad, grid_launches, 2 * launches))
