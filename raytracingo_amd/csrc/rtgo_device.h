@@ -885,11 +885,13 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
 #endif
             const bool ux = (tmx <= tmy) & (tmx <= tmz), uy = !ux & (tmy <= tmz);
             const float te = ux ? tmx : (uy ? tmy : tmz);
-            live = te <= tstop;
             tmx += ux ? tdx : 0.0f;
             tmy += uy ? tdy : 0.0f;
             tmz += (ux | uy) ? 0.0f : tdz;
             cell += ux ? sx : (uy ? sy : sz);
+            // (the range test is what ends the walk of a ray whose direction is not a number a walk can use -- an infinite component makes
+            // its reciprocal and with it the parameter per cell zero: te never grows -- and keeps every read inside the table)
+            live = (te <= tstop) & ((unsigned int)cell < (unsigned int)n_cells);
             if (live) e = cells[cell];
         }
         if (live) {
@@ -994,6 +996,7 @@ __device__ __attribute__((noinline)) float glossy_theta(float base, float expo)
 // (balls: 3.5 % of the pixels of a 96 x 64 frame left the tolerance when it ran lean, profiles/r03c).
 // have_x / Xpre: the tangent X of this direction is known already (a flat primitive's frame from build_kernel, bit for bit the value
 // computed here): lanes that have it skip the normalisation (a wave vote skips it altogether when every lane has).
+constexpr int kHemisphereMaxTries = 1024;   // (= ORACLE_HEMISPHERE_MAX_TRIES)
 template <bool LEAN_IN>
 __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coefficient, unsigned int& seed, bool have_x = false, v3 Xpre = v3{0.0f, 0.0f, 0.0f})
 {
@@ -1009,6 +1012,12 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
     else X = vnormalize(mk(Y.y - Y.z, -Y.x, Y.x));
     const v3 Z = vcross(Y, X);
     const float expo = div_cr(1.f, coefficient + 1.f);
+    // The reference's rejection loop (kernel.cu:109-120) is unbounded, and it never ends when the lobe lies wholly below the horizon of
+    // `normal`: kernel.cu:443-447 flips N by V = normalize(origin - x), which is rounding noise when t is tiny against the coordinates, and
+    // Rr = reflect about a wrongly flipped N (:508-510) points into the surface -- a mirror's lobe around it never passes the test and the
+    // launch hangs the GPU (tools/fuzz_farfield.py, random scene 45 seen 270 units off the origin).  kHemisphereMaxTries draws, then the
+    // last one stands; the oracle does the same, and wherever the reference's loop ends within that many draws nothing changes.
+    int tries = 0;
     do {
         const float r1 = rnd(seed);
         const float r2 = rnd(seed);
@@ -1039,7 +1048,7 @@ __device__ __forceinline__ v3 hemisphere(v3 normal, v3 direction, float coeffici
         }
         sincos_cr(phi, &sp, &cp);
         ray = vsub(vadd(vscale(X, st * cp), vscale(Y, ct)), vscale(Z, st * sp));
-    } while (vdot(normal, ray) < 0.f);
+    } while (vdot(normal, ray) < 0.f && ++tries < kHemisphereMaxTries);
     return ray;
 }
 

@@ -153,6 +153,31 @@ def test_hemisphere_sampling(oracle):
             assert float(out @ nrm) >= 0
 
 
+def test_hemisphere_rejection_loop_is_bounded(oracle):
+    """GetRayOnHemisphere's rejection loop (kernel.cu:109-120) has no bound, and it never ends when the lobe lies below the horizon of `normal`
+    -- which the closest-hit program can produce far from the origin (kernel.cu:443-447 flips N by rounding noise; the fixture below is such a
+    launch: a hung GPU before the bound).  Product and oracle stop after 1024 draws and keep the last one: a mirror lobe around
+    -normal comes back (pointing below the horizon, 2048 random numbers later); a launch whose every loop ends by itself is untouched
+    (test_committed_renders_reproduce_bitwise)."""
+    L = oracle.lib()
+    nrm = oracle.f32([0.0, 1.0, 0.0])
+    seed = C.c_uint32(99)
+    out = np.zeros(3, dtype=np.float32)
+    L.oracle_hemisphere(oracle.fptr(nrm), oracle.fptr(-nrm), 1e4, C.byref(seed), oracle.fptr(out))
+    assert np.isfinite(out).all() and float(out @ nrm) < -0.99
+    expect = C.c_uint32(99)
+    for _ in range(2 * 1024):
+        oracle.lib().oracle_rnd(C.byref(expect))
+    assert seed.value == expect.value
+    # the launch tools/fuzz_farfield.py hung on, by the oracle: it returns
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rejection_loop", "random45_far.npz"))
+    sc = oracle.scene_from_tables(fx["type"], fx["M"], fx["mat"], fx["lights"], fx["cam"], fx["bg"])
+    W, H = 128, 72
+    cam = fx["cam"].copy()
+    acc, img, rc = oracle.render(sc, oracle.frame(W, H, int(fx["n"]), 0, path=bool(fx["path"]), mode=1))
+    assert np.isfinite(acc).all() and rc["rays_total"] > W * H * int(fx["n"]) ** 2
+
+
 @pytest.mark.parametrize("name", ["cornell", "balls", "checkered", "slide"])
 def test_lbvh_invariants(oracle, name):
     t = oracle.scene_tables(oracle.scene(name, 64, 64))

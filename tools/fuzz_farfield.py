@@ -23,6 +23,7 @@ d_lo = float(sys.argv[3]) if len(sys.argv) > 3 else 50.0
 d_hi = float(sys.argv[4]) if len(sys.argv) > 4 else 600.0
 max_shift = float(sys.argv[5]) if len(sys.argv) > 5 else 400.0
 W, H = 512, 288
+VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))
 EDGES = [0, 20, 50, 100, 170, 300, 400, 500, 700, 1000, 2000, 5000, 1e9]
 QEDGES = [0, 1e3, 2e3, 4e3, 8e3, 1.6e4, 3.2e4, 6.4e4, 1.28e5, 2.56e5, 1e6, 1e7, 1e30]
 rays_by = np.zeros(len(EDGES) - 1, dtype=np.int64); bad_by = np.zeros(len(EDGES) - 1, dtype=np.int64); launches_by = np.zeros(len(EDGES) - 1, dtype=np.int64)
@@ -66,7 +67,13 @@ for seed in range(first, first + count):
     centre = np.asarray(shift, dtype=np.float64) + 0.0
     size = 14.0
     lib = ctx._lib
-    lib.rtgo_debug_cmpwalk.restype = C.c_int; lib.rtgo_debug_cmpwalk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    if not hasattr(lib, "rtgo_debug_cmpwalk"):          # (the product build: frames only, no ray-by-ray comparison)
+        class _NoCmp:
+            def rtgo_debug_cmpwalk(self, *a):
+                return 0
+        lib = _NoCmp()
+    else:
+        lib.rtgo_debug_cmpwalk.restype = C.c_int; lib.rtgo_debug_cmpwalk.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     buf = np.zeros((256, 16), np.float32)
     for trial in range(6):
         dist = float(np.exp(rng.uniform(np.log(d_lo), np.log(d_hi))))
@@ -79,8 +86,12 @@ for seed in range(first, first + count):
         O.lib().oracle_camera_uvw(O.fptr(eye), O.fptr(look), O.fptr(up), fov, np.float32(np.float32(W) / np.float32(H)), O.fptr(U), O.fptr(V), O.fptr(Wv))
         ctx.set_camera(eye, U, V, Wv)
         n = int(rng.choice([2, 3, 4])); path = bool(rng.integers(0, 4) != 0); amb = bool(rng.integers(0, 2)) and not path
+        if os.environ.get("FUZZ_ONLY_TRIAL") and trial != int(os.environ["FUZZ_ONLY_TRIAL"]):
+            continue          # (reproduce one launch: every random number above has been drawn)
         lib.rtgo_debug_cmpwalk(ctx._h, buf.ctypes.data, buf.nbytes)    # clear
         ctx.reset_stats()
+        if VERBOSE:
+            print("   %s seed %d trial %d: n %d path %s amb %s eye %s dist %.1f shift %s" % (name, seed, trial, n, path, amb, eye, dist, shift), flush=True)
         ctx.launch(capi.make_frame(W, H, n, 0, path, amb, stats=True)); ctx.sync()
         canon = ctx.read_accum(H, W).copy()
         st = ctx.stats()
@@ -104,6 +115,8 @@ for seed in range(first, first + count):
         # the product launch: the timed kernel inside the guard, the canonical walk without counters beyond it -- bit for bit the
         # instrumented frame either way
         ctx.reset_stats()
+        if VERBOSE:
+            print("      instrumented launch done: %d rays, %d disagreements; product launch" % (rays, k), flush=True)
         ctx.launch(capi.make_frame(W, H, n, 0, path, amb, stats=False)); ctx.sync()
         fast = ctx.read_accum(H, W)
         pst = ctx.stats()
