@@ -1213,8 +1213,10 @@ int rtgo_launch(rtgo_ctx* c, const rtgo_frame* f)
     const int max_wpe_work = units_per_wave4 >= 3 ? 5 : 4;
     int max_wpe = canon ? 4 : (int)env_uint("RTGO_MAX_WPE", (unsigned int)max_wpe_work);   // (experiment knob, clamped to what exists)
     max_wpe = max_wpe < 4 ? 4 : (max_wpe > 5 ? 5 : max_wpe);
+    int min_block = (int)env_uint("RTGO_MIN_BLOCK", 256);   // (experiment knob: 256 / 512 / 1024)
+    min_block = min_block >= 1024 ? 1024 : (min_block >= 512 ? 512 : 256);
     for (int w = 4; w <= max_wpe; ++w)
-        for (int b = 256; b <= kMaxBlock; b *= 2) {
+        for (int b = min_block; b <= kMaxBlock; b *= 2) {
             const size_t l = scene_lds + (stream ? (size_t)(b / 64) * 192 * kStreamWindow * sizeof(float) : 0) + (size_t)p.stack_depth * b * (canon ? sizeof(float2) : sizeof(unsigned int)) + (w >= 5 ? (size_t)b * (path ? 3 : 4) * kMaxLevels * sizeof(float) : 0);
             int per_cu = (int)((160 * 1024) / l);
             if (per_cu * (b / 64) > 4 * w) per_cu = (4 * w) / (b / 64);

@@ -874,6 +874,12 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
     const int NX = nx + 2, NXY = NX * (ny + 2);
     const int sx = fx ? 1 : -1, sy = fy ? NX : -NX, sz = fz ? NXY : -NXY;
     int cell = (cz + 1) * NXY + (cy + 1) * NX + cx + 1;
+    // A ray this walk cannot take -- an infinite or NaN component (its reciprocal, and with it the parameter per cell, is zero or no number:
+    // te would never grow), or a direction so long that a cell is crossed in less than the margin (the border argument above needs
+    // td > margin) -- is dropped here, once (1.4 % of balls' frame; a range test per step cost 4 %): every step then adds a positive td to the
+    // parameter it compares, so the loop ends, and it ends inside the table.  Such rays only exist where the arithmetic has broken down
+    // (far beyond the far-field guard, where the launch walks the canonical tree anyway).
+    live = live & (tdx > 2.0f * margin) & (tdy > 2.0f * margin) & (tdz > 2.0f * margin) & (fabsf(tmx + tmy + tmz) < 3e38f);
     float tstop = fminf(best.t, t1) + margin;   // the walk goes on while the current cell's exit lies before this
     int last = -1;                              // the record tested last: a shape that straddles two cells along the ray is listed in both
     unsigned int e = live ? cells[cell] : 0u;
@@ -885,13 +891,11 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
 #endif
             const bool ux = (tmx <= tmy) & (tmx <= tmz), uy = !ux & (tmy <= tmz);
             const float te = ux ? tmx : (uy ? tmy : tmz);
+            live = te <= tstop;
             tmx += ux ? tdx : 0.0f;
             tmy += uy ? tdy : 0.0f;
             tmz += (ux | uy) ? 0.0f : tdz;
             cell += ux ? sx : (uy ? sy : sz);
-            // (the range test is what ends the walk of a ray whose direction is not a number a walk can use -- an infinite component makes
-            // its reciprocal and with it the parameter per cell zero: te never grows -- and keeps every read inside the table)
-            live = (te <= tstop) & ((unsigned int)cell < (unsigned int)n_cells);
             if (live) e = cells[cell];
         }
         if (live) {
