@@ -1140,7 +1140,10 @@ __device__ __forceinline__ void cold_segment(const LaunchParams& p, unsigned int
 // WPE = waves per SIMD the register allocation targets: 4 (<= 128 VGPRs) for scenes whose LDS image limits a CU to 16 waves
 // anyway, 5 (<= 96 VGPRs, per-level path records in LDS) for small scenes, where the fifth wave buys more than the tighter
 // budget costs (rtgo_capi.hip picks per launch; kRenderKernels there lists every instantiation).
-constexpr int kStreamWindow = 4;   // STREAM: passes a lane may run ahead of the oldest pass that is still open (192 floats of LDS per wave each)
+#ifndef RTGO_STREAM_WINDOW
+#define RTGO_STREAM_WINDOW 4
+#endif
+constexpr int kStreamWindow = RTGO_STREAM_WINDOW;   // STREAM: passes a lane may run ahead of the oldest pass that is still open (192 floats of LDS per wave each)
 
 // COUNT: the canonical walk's V/T/h counters (collect_stats launches); the same walk without them serves launches beyond the
 // far-field guard, where it is the product path.
