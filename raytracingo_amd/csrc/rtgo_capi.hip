@@ -528,8 +528,8 @@ static int build_grid(rtgo_ctx* c, uint32_t n)
     // area, pays one step per cell and one test per list entry: cost = A_cell (n_cells + kTest entries) -- over every resolution
     // up to 32 per axis, with the entries counted exactly (a primitive's span of cells is separable per axis).  The entries term is what
     // matters: a resolution that cuts through the shapes lists them two to eight times (balls, profiles/r03r: 16 x 4 x 16, one sphere per
-    // column, 321 entries, 10.1 ms; 13 x 6 x 13, 754 entries, 13.8 ms; 32 x 1 x 32, 1024 entries, 19.1 ms; the tree 13.5).  kTest fitted there.
-    const float kTest = env_float("RTGO_GRID_KTEST", 1.7f), max_dup = env_float("RTGO_GRID_MAX_DUP", 3.0f);
+    // column, 321 entries, 10.1 ms; 13 x 6 x 13, 754 entries, 13.8 ms; 32 x 1 x 32, 1024 entries, 19.1 ms; the tree 13.5).  kTest: 1.7 fitted there; 1.0 since the walk tests a cell's box before its list (16 x 3 x 16, 9.7 ms).
+    const float kTest = env_float("RTGO_GRID_KTEST", 1.0f), max_dup = env_float("RTGO_GRID_MAX_DUP", 3.0f);
     const float pad0 = 2e-3f * (max_ext / 8.0f) + 1e-4f * reach_max;   // (the pad of the binning below depends on the cell size: close enough for counting)
     std::vector<uint8_t> span[3];
     for (int a = 0; a < 3; ++a) {
@@ -608,16 +608,48 @@ static int build_grid(rtgo_ctx* c, uint32_t n)
                 }
     }
     if ((float)total > (max_dup + 0.5f) * (float)ns || total > 60000) return RTGO_OK;   // (the binning's pad is a little larger than the count's)
-    const size_t bytes = ((size_t)g.n_cells * 4 + total * 2 + 31) / 32 * 32;
-    if (bytes > 32 * 1024) return RTGO_OK;
+    // image: [table, one word per cell][records, 2 float4 per listing cell][items, 16 bit each], each part on a 16-byte boundary
+    size_t n_rec = 0;
+    for (const std::vector<uint16_t>& l : lists) n_rec += l.empty() ? 0 : 1;
+    const size_t table_bytes = ((size_t)g.n_cells * 4 + 15) / 16 * 16, rec_bytes = n_rec * 32;
+    const size_t bytes = (table_bytes + rec_bytes + total * 2 + 31) / 32 * 32;
+    if (bytes > 40 * 1024) return RTGO_OK;
+    g.rec_off4 = (int)(table_bytes / 16);
+    g.items_off4 = (int)((table_bytes + rec_bytes) / 16);
     std::vector<unsigned char> img(bytes, 0);
     uint32_t* cells = reinterpret_cast<uint32_t*>(img.data());
-    uint16_t* items = reinterpret_cast<uint16_t*>(img.data() + (size_t)g.n_cells * 4);
-    size_t at = 0;
+    float* recs = reinterpret_cast<float*>(img.data() + table_bytes);
+    uint16_t* items = reinterpret_cast<uint16_t*>(img.data() + table_bytes + rec_bytes);
+    size_t at = 0, rec = 0;
     for (int k = 0; k < g.n_cells; ++k) {
         const std::vector<uint16_t>& l = lists[(size_t)k];
-        cells[k] = l.empty() ? 0u : (uint32_t)at | ((uint32_t)l.size() << 16);
-        for (uint16_t v : l) items[at++] = v;
+        if (l.empty()) continue;
+        cells[k] = (uint32_t)(rec + 1);
+        float* q = recs + 8 * rec;
+        for (int a = 0; a < 3; ++a) {
+            q[a] = 1e30f;
+            q[4 + a] = -1e30f;
+        }
+        for (uint16_t v : l) {
+            for (int a = 0; a < 3; ++a) {   // the box around what the cell lists: the shapes' own boxes grown by the pad ...
+                q[a] = std::fmin(q[a], box[v][a] - pad);
+                q[4 + a] = std::fmax(q[4 + a], box[v][3 + a] + pad);
+            }
+            items[at++] = v;
+        }
+        {   // ... cut to the cell, itself grown by the pad: a hit point lies (within the walk's rounding) in a cell the walk visits, that
+            // cell lists the shape, and the point is inside this box of it -- so the test happens there at the latest
+            const int kx = k % NX - 1, ky = (k / NX) % NY - 1, kz = k / (NX * NY) - 1;
+            const int kk[3] = {kx, ky, kz};
+            for (int a = 0; a < 3; ++a) {
+                q[a] = std::fmax(q[a], gmin[a] + gcs[a] * (float)kk[a] - pad);
+                q[4 + a] = std::fmin(q[4 + a], gmin[a] + gcs[a] * (float)(kk[a] + 1) + pad);
+            }
+        }
+        const uint32_t fc = (uint32_t)(at - l.size()) | ((uint32_t)l.size() << 16);
+        std::memcpy(&q[3], &fc, 4);
+        q[7] = 0.0f;
+        ++rec;
     }
     RTGO_HIP(c, hipMalloc(&c->grid.d, bytes));
     RTGO_HIP(c, hipMemcpyAsync(c->grid.d, img.data(), bytes, hipMemcpyHostToDevice, c->stream));

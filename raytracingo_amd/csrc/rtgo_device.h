@@ -47,6 +47,7 @@ struct GridParams {
     float min_x, min_y, min_z, cs_x, cs_y, cs_z, ics_x, ics_y, ics_z;   // lower corner, cell size, 1 / cell size
     int nx, ny, nz;                 // cells per axis (<= 32 each)
     int n_cells;                    // words of the table: (nx + 2) (ny + 2) (nz + 2), a border of empty cells around the grid
+    int rec_off4, items_off4;       // where the cell records and the item lists start, in float4 units from the table's start
     float margin;                   // fast_grid stops once the closest hit lies this far (in t) before the exit of the cell it is in
 };
 
@@ -844,8 +845,11 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
     // (everything of `g` into scalars first: it is wave-uniform, and a struct member read inside the loop through a reference went to scratch)
     const float gx = g.min_x, gy = g.min_y, gz = g.min_z, csx = g.cs_x, csy = g.cs_y, csz = g.cs_z, margin = g.margin;
     const int nx = g.nx, ny = g.ny, nz = g.nz, n_cells = g.n_cells;
+    // the table: one word per cell, 0 = lists nothing, else 1 + the index of the cell's record = two float4: the box around everything the
+    // cell lists (min.xyz | first item + count << 16, max.xyz | 0); then the items, 16-bit positions into fprims
     const unsigned int* __restrict__ cells = reinterpret_cast<const unsigned int*>(s_grid);
-    const unsigned short* __restrict__ items = reinterpret_cast<const unsigned short*>(cells + n_cells);
+    const float4* __restrict__ recs = s_grid + g.rec_off4;
+    const unsigned short* __restrict__ items = reinterpret_cast<const unsigned short*>(s_grid + g.items_off4);
     const float idx = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.x), -1e30f, 1e30f);   // (see fast_tree on 1 / 0)
     const float idy = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.y), -1e30f, 1e30f);
     const float idz = __builtin_amdgcn_fmed3f(__builtin_amdgcn_rcpf(d.z), -1e30f, 1e30f);
@@ -882,12 +886,29 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
     live = live & (tdx > 2.0f * margin) & (tdy > 2.0f * margin) & (tdz > 2.0f * margin) & (fabsf(tmx + tmy + tmz) < 3e38f);
     float tstop = fminf(best.t, t1) + margin;   // the walk goes on while the current cell's exit lies before this
     int last = -1;                              // the record tested last: a shape that straddles two cells along the ray is listed in both
-    unsigned int e = live ? cells[cell] : 0u;
+    // A lane stops at a cell only when its ray meets the box around what the cell lists (the conservative slab test of the tree walk):
+    // a sphere fills a tenth of its cell, and every stop is a test phase in which the lanes that did not stop wait.
+    const v3 id = mk(idx, idy, idz);
+    const v3 noid = mk(-(o.x * idx), -(o.y * idy), -(o.z * idz));
+    unsigned int fc = 0u;                       // first item | count << 16 of the cell this lane has stopped at, 0 = it has not
+    auto look = [&]() {
+        const unsigned int c = cells[cell];
+        if (c != 0u) {
+            const float4 q0 = recs[2u * c - 2u], q1 = recs[2u * c - 1u];
+            float tn;
+            fc = box_fast(q0, q1, id, noid, tmin, best.t, tn) ? __float_as_uint(q0.w) : 0u;
+        }
+    };
+    if (live) look();
     while (live) {
-        // to the next cell that lists something: out of the current one through the nearest of its three far planes
-        while (live && e == 0u) {
+        // to the next cell that lists something in the ray's way: out of the current one through the nearest of its three far planes
+        while (live && fc == 0u) {
 #ifdef RTGO_FAST_COUNTERS
+#if RTGO_FAST_COUNTERS == 2   /* wave-level: one count per executed iteration, whatever the number of live lanes */
+            dbg_boxes += (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) ? 1u : 0u;
+#else
             dbg_boxes += 1;
+#endif
 #endif
             const bool ux = (tmx <= tmy) & (tmx <= tmz), uy = !ux & (tmy <= tmz);
             const float te = ux ? tmx : (uy ? tmy : tmz);
@@ -896,14 +917,17 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
             tmy += uy ? tdy : 0.0f;
             tmz += (ux | uy) ? 0.0f : tdz;
             cell += ux ? sx : (uy ? sy : sz);
-            if (live) e = cells[cell];
+            if (live) look();
         }
         if (live) {
-            const int first = (int)(e & 0xFFFFu), cnt = (int)(e >> 16);
+            const int first = (int)(fc & 0xFFFFu), cnt = (int)(fc >> 16);
             for (int k = 0; k < cnt; ++k) {
                 const int pos = (int)items[first + k];
+#if defined(RTGO_FAST_COUNTERS) && RTGO_FAST_COUNTERS == 2
+                dbg_tests += (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) ? 1u : 0u;
+#endif
                 if (pos != last) {
-#ifdef RTGO_FAST_COUNTERS
+#if defined(RTGO_FAST_COUNTERS) && RTGO_FAST_COUNTERS != 2
                     dbg_tests += 1;
 #endif
                     if (spheres) sphere_leaf(s_fprims, pos, 1, o, d, tmin, best);
@@ -912,7 +936,7 @@ __device__ __forceinline__ void fast_grid(const float4* __restrict__ s_grid, con
                 last = pos;
             }
             tstop = fminf(best.t, t1) + margin;
-            e = 0u;   // (back into the stepping loop)
+            fc = 0u;   // (back into the stepping loop)
         }
     }
 }
