@@ -802,7 +802,11 @@ __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, c
             const float4 h0 = s_fnodes[2 * right], h1 = s_fnodes[2 * right + 1];
             float tl, tr;
 #ifdef RTGO_FAST_COUNTERS
+#if RTGO_FAST_COUNTERS == 2   /* wave-level: one count per executed node step / leaf phase, whatever the number of live lanes */
+            dbg_boxes += (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) ? 1u : 0u;
+#else
             dbg_boxes += 2;
+#endif
 #endif
             const bool hl = box_fast(l0, l1, id, noid, tmin, best.t, tl);
             const bool hr = box_fast(h0, h1, id, noid, tmin, best.t, tr);
@@ -823,7 +827,11 @@ __device__ __forceinline__ void fast_tree(const float4* __restrict__ s_fnodes, c
         if (have) {
             const int first = left, cnt = (-right) & 0xFFF, npairs = ((-right) >> 12) & 0xFF;   // leaf link = -(count | pairs << 12 | cuboid << 20)
 #ifdef RTGO_FAST_COUNTERS
+#if RTGO_FAST_COUNTERS == 2
+            dbg_tests += (__ffsll((long long)__ballot(true)) - 1 == (int)(threadIdx.x & 63u)) ? 1u : 0u;
+#else
             dbg_tests += (unsigned int)cnt;
+#endif
 #endif
             if (tree_spheres) sphere_leaf(s_fprims, first, cnt, o, d, tmin, best);
             else if (((-right) >> 20) != 0 && cub_mu > 0.0f) cuboid_range<false>(s_fprims, s_fprims, first, cub_mu, -INFINITY, o, d, tmin, best);
@@ -986,7 +994,7 @@ __device__ __forceinline__ bool closest_hit_fast(const float4* __restrict__ s_fn
     best.pos = -1;
     best.orig = -1;
     fast_list(s_fprims, g_fprims, n_small, n_prims, n_big_pairs, list_cub, cub_mu, o, d, tmin, best);
-#ifdef RTGO_FAST_COUNTERS
+#if defined(RTGO_FAST_COUNTERS) && RTGO_FAST_COUNTERS != 2
     dbg_tests += (unsigned int)(n_prims - n_small);
 #endif
 #ifdef RTGO_TIMELINE
