@@ -56,6 +56,7 @@ struct rtgo_ctx {
     struct Grid {
         void* d = nullptr;                 // n_cells words (first item | count << 16), then 16-bit items: positions into d_fprims
         int n_nodes = 0;                   // its size in 32-byte units (what LaunchParams::n_fnodes counts)
+        int entries = 0;                   // list entries (rtgo_debug_grid)
         rtgo::GridParams gp = {};
         float reach_max = 0.0f;            // the pad of the binning covers the walk's rounding for rays that start within this reach
         bool have = false;
@@ -324,6 +325,19 @@ static void box_screen_rect(const float* bounds, const LaunchParams& p, uint32_t
 
 extern "C" {
 
+// diagnostic (tests, tools; not part of include/rtgo.h): what rtgo_set_scene's grid build came to -- {has one, nx, ny, nz, list entries, bytes}
+extern "C" int rtgo_debug_grid(rtgo_ctx* c, int32_t out[6])
+{
+    if (!c || !out) return RTGO_E_INVALID;
+    out[0] = c->grid.have ? 1 : 0;
+    out[1] = c->grid.gp.nx;
+    out[2] = c->grid.gp.ny;
+    out[3] = c->grid.gp.nz;
+    out[4] = c->grid.entries;
+    out[5] = c->grid.n_nodes * 32;
+    return RTGO_OK;
+}
+
 #ifdef RTGO_CMPWALK
 // diagnostic build only (tools/cmp_walks.py): rays on which the canonical and the fast walk disagreed since the last call
 extern "C" int rtgo_debug_cmpwalk(rtgo_ctx* c, void* host, size_t bytes)
@@ -558,6 +572,7 @@ static int build_grid(rtgo_ctx* c, uint32_t n)
                 const uint8_t* sz = &span[2][(size_t)mz * ns];
                 for (int pos = 0; pos < ns; ++pos) entries += (size_t)sxy[pos] * sz[pos];
                 if ((float)entries > max_dup * (float)ns || words * 4 + entries * 2 > 32 * 1024) continue;
+                if (2 * mx * my * mz < ns) continue;   // (fewer cells than half the primitives: lists, not a grid)
                 const double cx = (ext[0] + 4.0 * pad0) / mx, cy = (ext[1] + 4.0 * pad0) / my, cz = (ext[2] + 4.0 * pad0) / mz;
                 const double cost = 2.0 * (cx * cy + cy * cz + cx * cz) * ((double)mx * my * mz + (double)kTest * (double)entries);
                 if (cost < best_cost) {
@@ -655,6 +670,7 @@ static int build_grid(rtgo_ctx* c, uint32_t n)
     RTGO_HIP(c, hipMemcpyAsync(c->grid.d, img.data(), bytes, hipMemcpyHostToDevice, c->stream));
     RTGO_HIP(c, hipStreamSynchronize(c->stream));
     c->grid.n_nodes = (int)(bytes / 32);
+    c->grid.entries = (int)total;
     c->grid.gp = g;
     c->grid.reach_max = reach_max;
     c->grid.have = true;

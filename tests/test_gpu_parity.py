@@ -1422,6 +1422,28 @@ def test_uniform_grid_walk_on_random_scenes(capi, oracle, kind, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_which_scenes_get_a_grid_and_at_what_resolution(capi, oracle):
+    """build_grid (rtgo_capi.hip) on the reference's scenes: balls -- 256 spheres, one per 1 x 1 column of the room -- gets the resolution the
+    cost search is there to find (16 columns each way: one sphere per column, at most a quarter of them listed twice: profiles/r03r, r03v);
+    checkered's 384 tile faces would be listed eight times each and get none; scenes of a few dozen primitives get none."""
+    import ctypes as C
+    got = {}
+    for name in ALL_SCENES:
+        sc, t, ctx = upload(capi, oracle, name, 64, 64)
+        out = (C.c_int32 * 6)()
+        ctx._lib.rtgo_debug_grid.restype = C.c_int
+        ctx._lib.rtgo_debug_grid.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        assert ctx._lib.rtgo_debug_grid(ctx._h, out) == 0
+        got[name] = list(out)
+        ctx.close()
+    print(got)
+    assert got["balls"][0] == 1 and got["balls"][1] == 16 and got["balls"][3] == 16 and 1 <= got["balls"][2] <= 4 and 256 <= got["balls"][4] <= 330, got["balls"]
+    for name in ALL_SCENES:
+        if name != "balls":
+            assert got[name][0] == 0, (name, got[name])
+
+
+@pytest.mark.gpu
 def test_uniform_grid_walk_on_balls(capi, oracle, monkeypatch):
     """balls (256 spheres in a room: the one reference scene whose grid the build keeps by default, 16 x 4 x 16 cells) where the reference puts it and moved
     off the origin (inside +-50: beyond, the CubeBox rule's boxes reach back to +-50, primitive.cpp:35-60, and the launch is the canonical walk's):
