@@ -370,7 +370,13 @@ def main():
                        "rays_per_frame": int(round(rays_per_launch)),
                        "rays_culled_per_frame": int(round(rays_culled / args.steps)),
                        "rays_traversed_per_frame": int(round(trav_per_launch)),
-                       "mrays_incl_culled_primary": round(rays_total / dt / 1e6, 2)},
+                       "mrays_incl_culled_primary": round(rays_total / dt / 1e6, 2),
+                       # what the timed launches ran (rank 0; rtgo_stats.last_variant): the launch-time trial of the spin-up chose it
+                       "kernel_variant": {"walk": ("canonical LBVH (beyond the far-field guard)" if st["last_variant"] & 4 else
+                                                   "uniform grid" if st["last_variant"] & 16 else
+                                                   "tree, big-primitive threshold 15 %" if st["last_variant"] & 2 else "tree, big-primitive threshold 36 %"),
+                                          "loop": "streaming" if st["last_variant"] & 1 else "lock-step",
+                                          "trial_launches_in_timed_region": int(st["launches_trial"])}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
