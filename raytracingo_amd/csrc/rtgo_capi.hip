@@ -508,8 +508,8 @@ int rtgo_set_stream(rtgo_ctx* c, void* hip_stream)
 // The uniform grid of rtgo::fast_grid over structure 0's small primitives (fprims [0, n_small)), from the boxes the fast walk culls
 // with (c->tight: build_kernel's, SBT order).  Every box is grown by `pad` before it is binned, and fast_grid stops `pad / 2` (in t)
 // late: the walk's own rounding (entry point, 96 accumulated steps: <= ~2e-5 of the rays' reach) stays an order of magnitude inside.
-// Cells: <= 32 per axis, table and lists within 32 KB of LDS; no grid for fewer than 64 small primitives (RTGO_GRID_MIN) or when every
-// resolution lists more than 3 entries per primitive (RTGO_GRID_MAX_DUP; a few big shapes among small ones: the tree's job).
+// Cells: <= 32 per axis; table, cell records and lists within 40 KB of LDS; no grid for fewer than 64 small primitives (RTGO_GRID_MIN) or when
+// every resolution with at least half as many cells as primitives lists more than 3 entries per primitive (RTGO_GRID_MAX_DUP; a few big shapes among small ones: the tree's job).
 static int build_grid(rtgo_ctx* c, uint32_t n)
 {
     c->grid.have = false;
@@ -571,7 +571,8 @@ static int build_grid(rtgo_ctx* c, uint32_t n)
                 size_t entries = 0;
                 const uint8_t* sz = &span[2][(size_t)mz * ns];
                 for (int pos = 0; pos < ns; ++pos) entries += (size_t)sxy[pos] * sz[pos];
-                if ((float)entries > max_dup * (float)ns || words * 4 + entries * 2 > 32 * 1024) continue;
+                const size_t listing = entries < (size_t)mx * my * mz ? entries : (size_t)mx * my * mz;   // (at most this many cells carry a record)
+                if ((float)entries > max_dup * (float)ns || words * 4 + listing * 32 + entries * 2 > 38 * 1024) continue;
                 if (2 * mx * my * mz < ns) continue;   // (fewer cells than half the primitives: lists, not a grid)
                 const double cx = (ext[0] + 4.0 * pad0) / mx, cy = (ext[1] + 4.0 * pad0) / my, cz = (ext[2] + 4.0 * pad0) / mz;
                 const double cost = 2.0 * (cx * cy + cy * cz + cx * cz) * ((double)mx * my * mz + (double)kTest * (double)entries);
